@@ -1,0 +1,237 @@
+"""MI355X-native image-stream blur engine — build + ctypes binding of the C ABI.
+
+The product is ``libmi_blur.so`` (HIP kernels for gfx950 behind ``include/mi_blur.h``)
+and the two C++ hosts under ``apps/``.  This module is only the harness-side binding
+used by tests/ and bench.py: it adds no behaviour of its own and has NO CPU fallback —
+if the shared library is missing or a GPU entry point is called without a GPU, it raises.
+
+The directory name contains hyphens, so import it with ``__graft_entry__.load_package()``
+(which registers it as module ``hoipe_amd``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG_DIR)
+CSRC = os.path.join(PKG_DIR, "csrc")
+APPS = os.path.join(PKG_DIR, "apps")
+LIB_PATH = os.path.join(PKG_DIR, "libmi_blur.so")
+HEADER = os.path.join(ROOT, "include", "mi_blur.h")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+DEVICE_CPU = -1
+VARIANT_AUTO, VARIANT_GENERIC, VARIANT_TILED = 0, 1, 2
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_NOMEM, ERR_STATE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+UNIQUE_ID_BYTES = 128
+
+
+def _newer(target: str, sources: list[str]) -> bool:
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def build_native(force: bool = False, verbose: bool = False) -> str:
+    """Compile libmi_blur.so (hipcc, --offload-arch=gfx950) and the C++ hosts, in-tree."""
+    srcs = [os.path.join(CSRC, f) for f in ("blur_kernels.hip", "mi_blur_api.cpp", "cpu_device.cpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("blur_launch.h", "cpu_device.h")] + [HEADER]
+    if force or not _newer(LIB_PATH, deps):
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra",
+               "-o", LIB_PATH] + srcs + ["-ldl", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    if os.path.isdir(APPS):
+        for app in ("heterogeneous_blur", "split_image_blur"):
+            src = os.path.join(APPS, app + ".cpp")
+            exe = os.path.join(APPS, app)
+            common = [os.path.join(APPS, f) for f in os.listdir(APPS) if f.endswith((".h", ".hpp"))]
+            if os.path.exists(src) and (force or not _newer(exe, [src, LIB_PATH, HEADER] + common)):
+                cmd = [HIPCC, "-O2", "-std=c++17", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), "-o", exe, src,
+                       "-L", PKG_DIR, "-lmi_blur", f"-Wl,-rpath,$ORIGIN/..", "-lpthread"]
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+def declared_symbols() -> list[str]:
+    """Every function include/mi_blur.h declares."""
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi_blur_[a-z0-9_]+)\s*\(", text)))
+
+
+class Timing(C.Structure):
+    _fields_ = [("h2d_ms", C.c_double), ("kernel_ms", C.c_double), ("d2h_ms", C.c_double),
+                ("bytes_h2d", C.c_uint64), ("bytes_d2h", C.c_uint64), ("bytes_alg", C.c_uint64),
+                ("images", C.c_uint64), ("launches", C.c_uint64)]
+
+    def as_dict(self) -> dict:
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class A2Geometry(C.Structure):
+    _fields_ = [(n, C.c_int) for n in
+                ("split_row", "cpu_input_rows", "cpu_output_rows", "gpu_input_rows", "gpu_output_rows")]
+
+
+class Band(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("row_begin", "row_end", "halo_top", "halo_bottom")]
+
+
+class MiBlurError(RuntimeError):
+    def __init__(self, status: int, what: str):
+        super().__init__(f"{what}: status {status} ({lib().mi_blur_strerror(status).decode()})")
+        self.status = status
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libmi_blur.so (raises if it has not been built — there is no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(LIB_PATH)
+    vp, i, u8p = C.c_void_p, C.c_int, C.c_void_p
+    sig = {
+        "mi_blur_strerror": (C.c_char_p, [i]),
+        "mi_blur_version": (i, []),
+        "mi_blur_device_count": (i, []),
+        "mi_blur_set_option": (i, [C.c_char_p, i]),
+        "mi_blur_enqueue": (i, [u8p, u8p, i, i, i, i, i, vp]),
+        "mi_blur_enqueue_band": (i, [u8p, u8p, i, i, i, i, i, i, vp]),
+        "mi_blur_enqueue_ex": (i, [u8p, u8p, i, i, i, i, i, i, i, i, vp]),
+        "mi_blur_create": (i, [C.POINTER(vp), i, i, i, i, i, i, i, i]),
+        "mi_blur_destroy": (None, [vp]),
+        "mi_blur_host_alloc": (vp, [C.c_size_t]),
+        "mi_blur_host_free": (None, [vp]),
+        "mi_blur_submit": (i, [vp, u8p, u8p, i]),
+        "mi_blur_submit_band": (i, [vp, u8p, u8p, i, i, i]),
+        "mi_blur_sync": (i, [vp, C.POINTER(Timing)]),
+        "mi_blur_reset_timing": (None, [vp]),
+        "mi_blur_resident_alloc": (i, [vp, i]),
+        "mi_blur_resident_fill_synthetic": (i, [vp, i]),
+        "mi_blur_resident_upload": (i, [vp, i, u8p, i]),
+        "mi_blur_resident_download": (i, [vp, i, u8p, i]),
+        "mi_blur_resident_in": (vp, [vp]),
+        "mi_blur_resident_out": (vp, [vp]),
+        "mi_blur_resident_run": (i, [vp, i, i, i]),
+        "mi_blur_cpu_run": (i, [u8p, u8p, i, i, i, i, i, i]),
+        "mi_blur_fill_synthetic": (None, [u8p, i, i, i, i, i, i]),
+        "mi_blur_fnv1a64": (C.c_uint64, [u8p, C.c_size_t]),
+        "mi_blur_a1_partition": (None, [i, i, C.c_float, C.POINTER(i), C.POINTER(i)]),
+        "mi_blur_shard_range": (None, [C.c_longlong, i, i, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+        "mi_blur_a2_split": (None, [i, C.c_float, i, C.POINTER(A2Geometry)]),
+        "mi_blur_band_of": (None, [i, i, i, i, C.POINTER(Band)]),
+        "mi_blur_comm_unique_id": (i, [vp]),
+        "mi_blur_comm_init_rank": (i, [C.POINTER(vp), i, i, vp]),
+        "mi_blur_comm_init_all": (i, [C.POINTER(vp), i, C.POINTER(i)]),
+        "mi_blur_comm_destroy": (None, [vp]),
+        "mi_blur_halo_exchange": (i, [vp, u8p, i, i, i, i, vp]),
+        "mi_blur_halo_exchange_all": (i, [C.POINTER(vp), i, C.POINTER(vp), i, i, C.POINTER(i), i, C.POINTER(vp)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)      # AttributeError if the library does not export it
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    return L
+
+
+def check(status: int, what: str = "mi_blur") -> None:
+    if status != OK:
+        raise MiBlurError(status, what)
+
+
+# ---- thin conveniences over the ABI (no logic beyond argument marshalling) -----------------
+def a1_partition(mode: int, batch_count: int, gpu_ratio: float) -> tuple[int, int]:
+    nc, ng = C.c_int(), C.c_int()
+    lib().mi_blur_a1_partition(mode, batch_count, gpu_ratio, C.byref(nc), C.byref(ng))
+    return nc.value, ng.value
+
+
+def shard_range(n_units: int, g: int, G: int) -> tuple[int, int]:
+    b, e = C.c_longlong(), C.c_longlong()
+    lib().mi_blur_shard_range(n_units, g, G, C.byref(b), C.byref(e))
+    return b.value, e.value
+
+
+def a2_split(height: int, gpu_ratio: float, halo: int = 1) -> dict:
+    g = A2Geometry()
+    lib().mi_blur_a2_split(height, gpu_ratio, halo, C.byref(g))
+    return {n: getattr(g, n) for n, _ in A2Geometry._fields_}
+
+
+def band_of(height: int, radius: int, g: int, G: int) -> dict:
+    b = Band()
+    lib().mi_blur_band_of(height, radius, g, G, C.byref(b))
+    return {n: getattr(b, n) for n, _ in Band._fields_}
+
+
+class Context:
+    """RAII wrapper of mi_blur_ctx for tests/bench."""
+
+    def __init__(self, device: int, width: int, height: int, channels: int, radius: int = 1,
+                 max_batch: int = 1, n_slots: int = 2, n_threads: int = 0):
+        self.h = C.c_void_p()
+        check(lib().mi_blur_create(C.byref(self.h), device, width, height, channels, radius, max_batch,
+                                   n_slots, n_threads), "mi_blur_create")
+        self.shape = (height, width, channels)
+        self.radius = radius
+
+    def close(self) -> None:
+        if self.h:
+            lib().mi_blur_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def submit(self, host_in, host_out, n_images: int) -> None:
+        check(lib().mi_blur_submit(self.h, host_in, host_out, n_images), "mi_blur_submit")
+
+    def submit_band(self, host_in, host_out, band_rows: int, halo_top: int, halo_bottom: int) -> None:
+        check(lib().mi_blur_submit_band(self.h, host_in, host_out, band_rows, halo_top, halo_bottom),
+              "mi_blur_submit_band")
+
+    def sync(self) -> dict:
+        t = Timing()
+        check(lib().mi_blur_sync(self.h, C.byref(t)), "mi_blur_sync")
+        return t.as_dict()
+
+    def reset_timing(self) -> None:
+        lib().mi_blur_reset_timing(self.h)
+
+    def resident_alloc(self, pool_images: int) -> None:
+        check(lib().mi_blur_resident_alloc(self.h, pool_images), "mi_blur_resident_alloc")
+
+    def resident_fill_synthetic(self, first_index: int = 0) -> None:
+        check(lib().mi_blur_resident_fill_synthetic(self.h, first_index), "mi_blur_resident_fill_synthetic")
+
+    def resident_upload(self, pool_index: int, host_in, n_images: int) -> None:
+        check(lib().mi_blur_resident_upload(self.h, pool_index, host_in, n_images), "mi_blur_resident_upload")
+
+    def resident_download(self, pool_index: int, host_out, n_images: int) -> None:
+        check(lib().mi_blur_resident_download(self.h, pool_index, host_out, n_images), "mi_blur_resident_download")
+
+    def resident_run(self, n_images: int, batch: int, timed: bool = False) -> None:
+        check(lib().mi_blur_resident_run(self.h, n_images, batch, int(timed)), "mi_blur_resident_run")

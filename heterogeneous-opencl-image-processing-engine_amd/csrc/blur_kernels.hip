@@ -1,0 +1,420 @@
+// blur_kernels.hip — gfx950 (MI355X / CDNA4) kernels of the image-stream blur engine.
+//
+// Replaces `__kernel gaussian_blur` (reference gaussian_kernel.cl:19-72): per pixel,
+// per channel, 3x3 {1,2,1}x{1,2,1}/16 (radius 1) or build-defined 5x5
+// {1,4,6,4,1}x{1,4,6,4,1}/256 (radius 2), clamp-to-edge (:56-57), truncation (:70),
+// on interleaved uint8 with pitch = width*channels (:60).
+//
+// The reference accumulates in float; every weight is dyadic and every partial sum a
+// multiple of 2^-4 (2^-8) below 2^24, so the result equals the integer form
+// (sum w_i p_i) >> 4 (>> 8) in ANY summation order.  That licenses what the tiled
+// kernel does: separable passes in packed 16-bit integers.
+//
+// Tiled kernel (bandwidth-bound stencil, no MFMA):
+//   * a row is treated as a byte stream of pitch bytes; the x-neighbours of byte b are
+//     b-C and b+C, so interleaved RGB needs no de-interleave;
+//   * one workgroup stages a (TH + 2R) x (ncols + 2) tile of 16-byte chunks in LDS —
+//     the output tile plus an R-row halo above/below (rows clamped at the band edge at
+//     staging time, so the y-clamp costs nothing later) and one 16-byte halo chunk left
+//     and right — with 16 B/lane coalesced loads, either LDS-DMA (global_load_lds_dwordx4,
+//     no VGPR round trip) or registers;
+//   * each thread owns one 16-byte chunk column and RPG consecutive rows: per row it
+//     reads 8+16+8 bytes from LDS, forms the horizontal sums of its 16 output bytes in
+//     packed u16 (v_alignbyte_b32 for the +-C / +-2C byte shifts, v_perm_b32 to widen,
+//     v_pk_* arithmetic), keeps a 2R+1-row sliding window of those sums in registers,
+//     combines vertically, narrows with one v_perm_b32 per dword and stores 16 bytes;
+//   * the x-clamp is synthesised in registers only by the lanes whose chunk touches the
+//     row start/end (byte at position -k equals byte (-k mod C); mirror at the end).
+//   HBM traffic = each input byte once + each output byte once, plus the tile-edge halo
+//   (2R/TH of the rows, 2/ncols of the columns), which neighbouring tiles keep in L2
+//   (blockIdx -> tile map gives each XCD a contiguous run of tiles).
+//
+// Generic kernel: one output byte per thread, any shape (pitch not a multiple of 16,
+// unaligned pointers).  Correct everywhere, fast nowhere.
+#include "blur_launch.h"
+#include "../../include/mi_blur.h"
+
+#include <hip/hip_ext.h>
+#include <limits.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace mi_blur {
+
+// ----------------------------------------------------------------------------------
+// device helpers
+// ----------------------------------------------------------------------------------
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u16x2 as_pk(uint32_t x) { return __builtin_bit_cast(u16x2, x); }
+__device__ __forceinline__ uint32_t as_u32(u16x2 x) { return __builtin_bit_cast(uint32_t, x); }
+// bytes (b0,b1,b2,b3) -> (b0 | b1<<16) and (b2 | b3<<16); selector 0x0c = constant 0x00
+__device__ __forceinline__ u16x2 widen_lo(uint32_t x) { return as_pk(__builtin_amdgcn_perm(0u, x, 0x0c010c00u)); }
+__device__ __forceinline__ u16x2 widen_hi(uint32_t x) { return as_pk(__builtin_amdgcn_perm(0u, x, 0x0c030c02u)); }
+// high bytes of four u16 (lo pair, hi pair) -> one dword of 4 output bytes
+__device__ __forceinline__ uint32_t narrow_hi8(u16x2 lo, u16x2 hi)
+{
+    return __builtin_amdgcn_perm(as_u32(hi), as_u32(lo), 0x07050301u);
+}
+
+// x-clamp selectors.  Left: the dword holding row-stream bytes [-4q, -4q+3] (q = 1, 2)
+// when the chunk starts the row: byte at position p < 0 is a copy of byte (p mod C)
+// (pixel x<0 clamps to x=0, same channel).  All indices address bytes of chunk dword 0.
+constexpr uint32_t sel_left(int C, int q)
+{
+    uint32_t s = 0;
+    for (int j = 0; j < 4; j++) {
+        int p = -4 * q + j;
+        int idx = ((p % C) + C) % C;
+        s |= (uint32_t)idx << (8 * j);
+    }
+    return s;
+}
+// Right: the dword holding bytes [pitch+4q, pitch+4q+3] (q = 0, 1) when the chunk ends
+// the row: byte pitch+k is a copy of byte pitch-C+(k mod C).  Indices address bytes of
+// chunk dword 3 (row bytes pitch-4 .. pitch-1).
+constexpr uint32_t sel_right(int C, int q)
+{
+    uint32_t s = 0;
+    for (int j = 0; j < 4; j++) {
+        int k = 4 * q + j;
+        int idx = 4 - C + (k % C);
+        s |= (uint32_t)idx << (8 * j);
+    }
+    return s;
+}
+
+// w[0..7] = row-stream bytes [-8, 24) around this thread's chunk (chunk = w[2..5]).
+// Returns the dword of bytes [4*I + K, 4*I + K + 4).
+template <int K, int I>
+__device__ __forceinline__ uint32_t shifted(const uint32_t (&w)[8])
+{
+    constexpr int pos = 8 + 4 * I + K;
+    static_assert(pos >= 0 && pos <= 28, "shift out of the staged window");
+    constexpr int q = pos >> 2, s = pos & 3;
+    if constexpr (s == 0) return w[q];
+    else return __builtin_amdgcn_alignbyte(w[q + 1], w[q], s);
+}
+
+// Horizontal tap sums of one chunk dword I: two packed-u16 pairs.
+template <int C, int R, int I>
+__device__ __forceinline__ void hsum_dword(const uint32_t (&w)[8], u16x2 &lo, u16x2 &hi)
+{
+    const uint32_t c = w[2 + I];
+    if constexpr (R == 1) {
+        const uint32_t l = shifted<-C, I>(w), r = shifted<C, I>(w);
+        lo = widen_lo(l) + widen_lo(r) + widen_lo(c) * (unsigned short)2;
+        hi = widen_hi(l) + widen_hi(r) + widen_hi(c) * (unsigned short)2;
+    } else {
+        const uint32_t l2 = shifted<-2 * C, I>(w), l1 = shifted<-C, I>(w);
+        const uint32_t r1 = shifted<C, I>(w), r2 = shifted<2 * C, I>(w);
+        lo = (widen_lo(l2) + widen_lo(r2)) + (widen_lo(l1) + widen_lo(r1)) * (unsigned short)4 +
+             widen_lo(c) * (unsigned short)6;
+        hi = (widen_hi(l2) + widen_hi(r2)) + (widen_hi(l1) + widen_hi(r1)) * (unsigned short)4 +
+             widen_hi(c) * (unsigned short)6;
+    }
+}
+
+// Horizontal pass of one staged LDS row for this thread's chunk: h[0..7] = 16 sums.
+template <int C, int R>
+__device__ __forceinline__ void hrow(const uint8_t *lp, bool at_start, bool at_end, u16x2 (&h)[8])
+{
+    uint32_t w[8];
+    const uint2 a = *reinterpret_cast<const uint2 *>(lp - 8);
+    const uint4 c = *reinterpret_cast<const uint4 *>(lp);
+    const uint2 b = *reinterpret_cast<const uint2 *>(lp + 16);
+    w[0] = a.x; w[1] = a.y; w[2] = c.x; w[3] = c.y; w[4] = c.z; w[5] = c.w; w[6] = b.x; w[7] = b.y;
+    if (at_start) {
+        w[1] = __builtin_amdgcn_perm(0u, w[2], sel_left(C, 1));
+        w[0] = __builtin_amdgcn_perm(0u, w[2], sel_left(C, 2));
+    }
+    if (at_end) {
+        w[6] = __builtin_amdgcn_perm(0u, w[5], sel_right(C, 0));
+        w[7] = __builtin_amdgcn_perm(0u, w[5], sel_right(C, 1));
+    }
+    hsum_dword<C, R, 0>(w, h[0], h[1]);
+    hsum_dword<C, R, 1>(w, h[2], h[3]);
+    hsum_dword<C, R, 2>(w, h[4], h[5]);
+    hsum_dword<C, R, 3>(w, h[6], h[7]);
+}
+
+struct TiledParams {
+    const uint8_t *in;
+    uint8_t *out;
+    long long in_stride, out_stride;  // bytes per image
+    int pitch, cpr;                   // bytes per row, 16-byte chunks per row
+    int H, y0, y1;                    // band rows (clamp range), output rows [y0,y1)
+    int ncols, nstrips;               // chunk columns per strip, strips per row
+    int TH, ntiles_y, ngroups;        // output rows per tile, row tiles per image, row groups per tile
+    unsigned nblocks;
+    int xcd;
+};
+
+// ----------------------------------------------------------------------------------
+// LDS-tiled vector kernel
+// ----------------------------------------------------------------------------------
+template <int C, int R, int RPG, bool DMA>
+__global__ __launch_bounds__(256) void blur_tiled_kernel(const TiledParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int t = threadIdx.x, NT = blockDim.x;
+
+    // blockIdx -> tile.  Blocks b and b+8 share an XCD (round-robin dispatch); give each
+    // XCD a contiguous run of tiles so tile-edge halo rows are L2 hits.  Speed only.
+    unsigned L = blockIdx.x;
+    if (p.xcd) {
+        const unsigned n = p.nblocks, q = n >> 3, r = n & 7u, x = L & 7u, k = L >> 3;
+        L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+    }
+    const int strip = (int)(L % (unsigned)p.nstrips);
+    const unsigned t2 = L / (unsigned)p.nstrips;
+    const int ty = (int)(t2 % (unsigned)p.ntiles_y);
+    const int img = (int)(t2 / (unsigned)p.ntiles_y);
+
+    const int ty0 = p.y0 + ty * p.TH;                 // first output row of the tile (band coords)
+    const int rows_out = min(p.TH, p.y1 - ty0);
+    const int x0c = strip * p.ncols;                  // first chunk column of the strip
+    const int nc = min(p.ncols, p.cpr - x0c);
+    const int cpr2 = nc + 2;                          // + one halo chunk each side
+    const int nchunks = (rows_out + 2 * R) * cpr2;
+    const uint8_t *img_in = p.in + (long long)img * p.in_stride;
+
+    // ---- stage: LDS chunk i <-> (row i / cpr2, column i % cpr2); rows clamp to the band.
+    {
+        int row = t / cpr2, cc = t - row * cpr2;
+        const int drow = NT / cpr2, dcc = NT - drow * cpr2;
+        for (int i = t; i < nchunks; i += NT) {
+            const int sr = min(max(ty0 - R + row, 0), p.H - 1);
+            const int sc = min(max(x0c + cc - 1, 0), p.cpr - 1);
+            const uint8_t *g = img_in + (size_t)sr * (size_t)p.pitch + (size_t)sc * 16u;
+            if constexpr (DMA) {
+                // LDS destination = wave-uniform base + lane*16; lanes hold consecutive i.
+                uint8_t *base = lds + (size_t)(i - (t & 63)) * 16u;
+                __builtin_amdgcn_global_load_lds(
+                    (const void __attribute__((address_space(1))) *)g,
+                    (void __attribute__((address_space(3))) *)base, 16, 0, 0);
+            } else {
+                *reinterpret_cast<uint4 *>(lds + (size_t)i * 16u) = *reinterpret_cast<const uint4 *>(g);
+            }
+            row += drow; cc += dcc;
+            if (cc >= cpr2) { cc -= cpr2; row++; }
+        }
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+
+    // ---- compute: thread = (chunk column col, row group grp); RPG rows, sliding window.
+    const int grp = t / nc, col = t - grp * nc;
+    const int r0 = grp * RPG;
+    if (grp >= p.ngroups || r0 >= rows_out) return;   // no barrier below
+    const bool at_start = (x0c + col) == 0;
+    const bool at_end = (x0c + col) == p.cpr - 1;
+    const int lrow = cpr2 * 16;
+    const uint8_t *lp = lds + ((size_t)r0 * cpr2 + (col + 1)) * 16u;
+    uint8_t *op = p.out + (long long)img * p.out_stride +
+                  (size_t)(ty0 - p.y0 + r0) * (size_t)p.pitch + (size_t)(x0c + col) * 16u;
+
+    constexpr int WIN = 2 * R + 1;
+    u16x2 hw[WIN][8];
+#pragma unroll
+    for (int k = 0; k < 2 * R; k++) hrow<C, R>(lp + k * lrow, at_start, at_end, hw[k]);
+
+#pragma unroll
+    for (int r = 0; r < RPG; r++) {
+        hrow<C, R>(lp + (r + 2 * R) * lrow, at_start, at_end, hw[(r + 2 * R) % WIN]);
+        u16x2 o[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if constexpr (R == 1) {
+                // (h0 + 2 h1 + h2) * 16: result byte = high byte of each u16 (max 65280)
+                o[j] = ((hw[r % WIN][j] + hw[(r + 2) % WIN][j]) << (unsigned short)4) +
+                       (hw[(r + 1) % WIN][j] << (unsigned short)5);
+            } else {
+                // h0 + 4 h1 + 6 h2 + 4 h3 + h4 (max 65280), >> 8 = high byte
+                o[j] = (hw[r % WIN][j] + hw[(r + 4) % WIN][j]) +
+                       ((hw[(r + 1) % WIN][j] + hw[(r + 3) % WIN][j]) << (unsigned short)2) +
+                       hw[(r + 2) % WIN][j] * (unsigned short)6;
+            }
+        }
+        if (r0 + r < rows_out) {
+            uint4 v;
+            v.x = narrow_hi8(o[0], o[1]); v.y = narrow_hi8(o[2], o[3]);
+            v.z = narrow_hi8(o[4], o[5]); v.w = narrow_hi8(o[6], o[7]);
+            *reinterpret_cast<uint4 *>(op + (size_t)r * (size_t)p.pitch) = v;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// generic kernel: one output byte per thread
+// ----------------------------------------------------------------------------------
+struct GenericParams {
+    const uint8_t *in;
+    uint8_t *out;
+    long long in_stride, out_stride, total;
+    int width, channels, pitch;
+    int H, y0;
+};
+
+template <int R>
+__global__ __launch_bounds__(256) void blur_generic_kernel(const GenericParams p)
+{
+    constexpr int T1[3] = {1, 2, 1};
+    constexpr int T2[5] = {1, 4, 6, 4, 1};
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < p.total; idx += step) {
+        const long long img = idx / p.out_stride;
+        const long long rem = idx - img * p.out_stride;
+        const int y = p.y0 + (int)(rem / p.pitch);
+        const int b = (int)(rem % p.pitch);
+        const int x = b / p.channels, c = b - x * p.channels;
+        const uint8_t *src = p.in + img * p.in_stride;
+        unsigned sum = 0;
+#pragma unroll
+        for (int ky = -R; ky <= R; ky++) {
+            const int ny = min(max(y + ky, 0), p.H - 1);
+            const uint8_t *rowp = src + (size_t)ny * (size_t)p.pitch + c;
+#pragma unroll
+            for (int kx = -R; kx <= R; kx++) {
+                const int nx = min(max(x + kx, 0), p.width - 1);
+                const int wgt = (R == 1) ? T1[ky + R] * T1[kx + R] : T2[ky + R] * T2[kx + R];
+                sum += (unsigned)rowp[(size_t)nx * (size_t)p.channels] * (unsigned)wgt;
+            }
+        }
+        p.out[idx] = (uint8_t)(sum >> (R == 1 ? 4 : 8));
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------------
+Tunables &tunables()
+{
+    static Tunables t = [] {
+        Tunables v{1, 8, 1};
+        if (const char *e = getenv("MI_BLUR_STAGE")) v.stage_dma = strcmp(e, "reg") != 0;
+        if (const char *e = getenv("MI_BLUR_RPG")) v.rpg = atoi(e) == 16 ? 16 : 8;
+        if (const char *e = getenv("MI_BLUR_XCD")) v.xcd_remap = atoi(e) != 0;
+        return v;
+    }();
+    return t;
+}
+
+bool tiled_eligible(const void *in, const void *out, int width, int channels)
+{
+    if (channels < 1 || channels > 4) return false;
+    const long long pitch = (long long)width * channels;
+    return (pitch % 16 == 0) && ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0);
+}
+
+static inline int hip_status(hipError_t e) { return e == hipSuccess ? MI_BLUR_OK : MI_BLUR_ERR_HIP_BASE - (int)e; }
+
+template <typename K, typename P>
+static int do_launch(K kernel, dim3 grid, dim3 block, size_t lds, const LaunchDesc &d, const P &params)
+{
+    if (d.start || d.stop)
+        hipExtLaunchKernelGGL(kernel, grid, block, lds, d.stream, d.start, d.stop, 0, params);
+    else
+        hipLaunchKernelGGL(kernel, grid, block, lds, d.stream, params);
+    return hip_status(hipGetLastError());
+}
+
+template <int C, int R>
+static int launch_tiled_cr(const LaunchDesc &d, const TiledParams &p, dim3 grid, dim3 block, size_t lds,
+                           int rpg, bool dma)
+{
+    if (rpg == 16)
+        return dma ? do_launch(blur_tiled_kernel<C, R, 16, true>, grid, block, lds, d, p)
+                   : do_launch(blur_tiled_kernel<C, R, 16, false>, grid, block, lds, d, p);
+    return dma ? do_launch(blur_tiled_kernel<C, R, 8, true>, grid, block, lds, d, p)
+               : do_launch(blur_tiled_kernel<C, R, 8, false>, grid, block, lds, d, p);
+}
+
+template <int R>
+static int launch_tiled_r(const LaunchDesc &d, const TiledParams &p, dim3 grid, dim3 block, size_t lds,
+                          int rpg, bool dma)
+{
+    switch (d.channels) {
+    case 1: return launch_tiled_cr<1, R>(d, p, grid, block, lds, rpg, dma);
+    case 2: return launch_tiled_cr<2, R>(d, p, grid, block, lds, rpg, dma);
+    case 3: return launch_tiled_cr<3, R>(d, p, grid, block, lds, rpg, dma);
+    case 4: return launch_tiled_cr<4, R>(d, p, grid, block, lds, rpg, dma);
+    }
+    return MI_BLUR_ERR_INVALID;
+}
+
+static int launch_tiled(const LaunchDesc &d)
+{
+    const Tunables &tun = tunables();
+    const int R = d.radius, rpg = tun.rpg;
+    const int pitch = d.width * d.channels, cpr = pitch / 16, rows = d.y1 - d.y0;
+
+    TiledParams p{};
+    p.in = d.in; p.out = d.out;
+    p.in_stride = (long long)d.band_rows * pitch;
+    p.out_stride = (long long)rows * pitch;
+    p.pitch = pitch; p.cpr = cpr; p.H = d.band_rows; p.y0 = d.y0; p.y1 = d.y1;
+    p.nstrips = (cpr + 63) / 64;
+    p.ncols = (cpr + p.nstrips - 1) / p.nstrips;
+
+    // Row groups per tile: the most efficient split of the rows (fewest idle row slots
+    // and idle lanes), within 256 threads and 64 KiB of LDS.
+    const int maxg = 256 / p.ncols, need = (rows + rpg - 1) / rpg;
+    int best_g = 1; double best = -1.0;
+    for (int g = 1; g <= maxg && g <= need; g++) {
+        const size_t lds = (size_t)(g * rpg + 2 * R) * (p.ncols + 2) * 16;
+        if (lds > 64 * 1024) break;
+        const int nt = (p.ncols * g + 63) / 64 * 64;
+        const int tiles = (rows + g * rpg - 1) / (g * rpg);
+        const double eff = (double)rows / ((double)tiles * g * rpg) * ((double)p.ncols * g / nt);
+        if (eff >= best - 1e-9) { best = eff; best_g = g; }
+    }
+    p.ngroups = best_g;
+    p.TH = best_g * rpg;
+    p.ntiles_y = (rows + p.TH - 1) / p.TH;
+    const long long nblocks = (long long)d.n_images * p.ntiles_y * p.nstrips;
+    if (nblocks > 0x7fffffffLL) return MI_BLUR_ERR_INVALID;
+    p.nblocks = (unsigned)nblocks;
+    p.xcd = tun.xcd_remap && nblocks >= 16;
+
+    const dim3 grid((unsigned)nblocks), block((unsigned)((p.ncols * p.ngroups + 63) / 64 * 64));
+    const size_t lds = (size_t)(p.TH + 2 * R) * (p.ncols + 2) * 16;
+    return R == 1 ? launch_tiled_r<1>(d, p, grid, block, lds, rpg, tun.stage_dma != 0)
+                  : launch_tiled_r<2>(d, p, grid, block, lds, rpg, tun.stage_dma != 0);
+}
+
+static int launch_generic(const LaunchDesc &d)
+{
+    GenericParams p{};
+    const int pitch = d.width * d.channels, rows = d.y1 - d.y0;
+    p.in = d.in; p.out = d.out;
+    p.in_stride = (long long)d.band_rows * pitch;
+    p.out_stride = (long long)rows * pitch;
+    p.total = p.out_stride * d.n_images;
+    p.width = d.width; p.channels = d.channels; p.pitch = pitch; p.H = d.band_rows; p.y0 = d.y0;
+    long long blocks = (p.total + 255) / 256;
+    if (blocks > 256LL * 64) blocks = 256LL * 64;   // grid-stride the rest
+    const dim3 grid((unsigned)blocks), block(256);
+    return d.radius == 1 ? do_launch(blur_generic_kernel<1>, grid, block, 0, d, p)
+                         : do_launch(blur_generic_kernel<2>, grid, block, 0, d, p);
+}
+
+int launch(const LaunchDesc &d)
+{
+    if (!d.in || !d.out || d.in == d.out) return MI_BLUR_ERR_INVALID;
+    if (d.width <= 0 || d.band_rows <= 0 || d.channels <= 0 || d.n_images < 0) return MI_BLUR_ERR_INVALID;
+    if (d.radius != 1 && d.radius != 2) return MI_BLUR_ERR_INVALID;
+    if (d.y0 < 0 || d.y1 > d.band_rows || d.y0 >= d.y1) return MI_BLUR_ERR_INVALID;
+    if ((long long)d.width * d.channels > INT_MAX / 2) return MI_BLUR_ERR_INVALID;
+    if ((long long)d.width * d.channels * d.band_rows > INT_MAX) return MI_BLUR_ERR_INVALID;  // per-image 32-bit
+    if (d.n_images == 0) return MI_BLUR_OK;
+    const bool can_tile = tiled_eligible(d.in, d.out, d.width, d.channels);
+    switch (d.variant) {
+    case MI_BLUR_VARIANT_AUTO: return can_tile ? launch_tiled(d) : launch_generic(d);
+    case MI_BLUR_VARIANT_GENERIC: return launch_generic(d);
+    case MI_BLUR_VARIANT_TILED: return can_tile ? launch_tiled(d) : MI_BLUR_ERR_INVALID;
+    }
+    return MI_BLUR_ERR_INVALID;
+}
+
+}  // namespace mi_blur

@@ -1,0 +1,31 @@
+// blur_launch.h — internal (not part of the C ABI): launch interface between
+// mi_blur_api.cpp and the gfx950 kernels in blur_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mi_blur {
+
+struct LaunchDesc {
+    const uint8_t *in;      // device, n_images bands of band_rows rows, laid end to end
+    uint8_t *out;           // device, n_images blocks of (y1-y0) rows
+    int width, band_rows, channels, radius;
+    int n_images;
+    int y0, y1;             // output rows [y0,y1) of each band
+    int variant;            // mi_blur_variant
+    hipStream_t stream;
+    hipEvent_t start, stop; // optional: dispatch start/stop timestamps (hipExtLaunchKernel)
+};
+
+// Returns MI_BLUR_OK or a negative mi_blur_status.
+int launch(const LaunchDesc &d);
+
+// True when the LDS-tiled vector kernel can take this shape.
+bool tiled_eligible(const void *in, const void *out, int width, int channels);
+
+// Tunables: defaults from env (MI_BLUR_STAGE=dma|reg, MI_BLUR_RPG=8|16, MI_BLUR_XCD=0|1),
+// changeable at run time through mi_blur_set_option.
+struct Tunables { int stage_dma; int rpg; int xcd_remap; };
+Tunables &tunables();
+
+}  // namespace mi_blur

@@ -1,0 +1,126 @@
+// cpu_device.cpp — the engine's host-thread device and host-side helpers.
+//
+// The reference runs the same OpenCL kernel on a CL_DEVICE_TYPE_CPU device
+// (heterogeneous_blur.c:170-176,507).  ROCm's OpenCL has no CPU device, so the
+// `cpu` / `both` modes run this native implementation instead: same arithmetic
+// (integer form of gaussian_kernel.cl:19-72, see blur_kernels.hip header), rows
+// processed separably with an edge-replicated scratch row so the inner loops are
+// branch-free and auto-vectorise.  This is a DEVICE THE CALLER ASKS FOR BY NAME
+// (MI_BLUR_DEVICE_CPU), never a fallback for a missing GPU, and it shares no code
+// with oracle/ (which is test infrastructure).
+#include "cpu_device.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace mi_blur {
+
+int hardware_threads()
+{
+    unsigned n = std::thread::hardware_concurrency();
+    return n ? (int)n : 1;
+}
+
+// Rows [y_begin, y_end) of one image / band of H rows.
+void cpu_blur_rows(const uint8_t *in, uint8_t *out, int W, int H, int C, int R, int y_begin, int y_end,
+                   int out_row_shift)
+{
+    const int pitch = W * C, pad = R * C;
+    std::vector<uint16_t> scratch((size_t)pitch + 2 * pad);
+    uint16_t *v = scratch.data() + pad;               // v[-pad .. pitch+pad)
+    for (int y = y_begin; y < y_end; y++) {
+        // vertical pass: v[b] = sum_k taps[k] * in[clamp(y+k)][b]   (<= 4080)
+        const uint8_t *rows[5];
+        for (int k = -R; k <= R; k++) rows[k + R] = in + (size_t)std::min(std::max(y + k, 0), H - 1) * pitch;
+        if (R == 1) {
+            const uint8_t *a = rows[0], *b = rows[1], *c = rows[2];
+            for (int i = 0; i < pitch; i++) v[i] = (uint16_t)(a[i] + 2 * b[i] + c[i]);
+        } else {
+            const uint8_t *a = rows[0], *b = rows[1], *c = rows[2], *d = rows[3], *e = rows[4];
+            for (int i = 0; i < pitch; i++) v[i] = (uint16_t)(a[i] + e[i] + 4 * (b[i] + d[i]) + 6 * c[i]);
+        }
+        // clamp-to-edge in x == replicate the first/last pixel's channels outward
+        for (int k = 1; k <= pad; k++) {
+            v[-k] = v[((-k % C) + C) % C];
+            v[pitch + k - 1] = v[pitch - C + ((k - 1) % C)];
+        }
+        // horizontal pass on the 16-bit sums, one truncating shift (gaussian_kernel.cl:70)
+        uint8_t *o = out + (size_t)(y - out_row_shift) * pitch;
+        if (R == 1) {
+            for (int i = 0; i < pitch; i++) o[i] = (uint8_t)((v[i - C] + 2 * v[i] + v[i + C]) >> 4);
+        } else {
+            for (int i = 0; i < pitch; i++)
+                o[i] = (uint8_t)((v[i - 2 * C] + v[i + 2 * C] + 4 * (v[i - C] + v[i + C]) + 6 * v[i]) >> 8);
+        }
+    }
+}
+
+// n_images bands of band_rows rows; output rows [y0,y1) of each.  Threads take whole
+// images when there are enough of them, else row slices of each image.
+void cpu_blur_batch(const uint8_t *in, uint8_t *out, int W, int band_rows, int C, int R, int n_images,
+                    int y0, int y1, int n_threads)
+{
+    if (n_images <= 0) return;
+    if (n_threads <= 0) n_threads = hardware_threads();
+    const size_t in_stride = (size_t)W * C * band_rows, out_stride = (size_t)W * C * (y1 - y0);
+    const int rows = y1 - y0;
+    // work items: (image, row slice)
+    int slices = 1;
+    if (n_images < n_threads) slices = std::min(rows, (n_threads + n_images - 1) / n_images);
+    const long long items = (long long)n_images * slices;
+    std::atomic<long long> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            const long long it = next.fetch_add(1, std::memory_order_relaxed);
+            if (it >= items) break;
+            const int img = (int)(it / slices), s = (int)(it % slices);
+            const int ys = y0 + (int)((long long)rows * s / slices), ye = y0 + (int)((long long)rows * (s + 1) / slices);
+            cpu_blur_rows(in + img * in_stride, out + img * out_stride, W, band_rows, C, R, ys, ye, y0);
+        }
+    };
+    const int nt = (int)std::min<long long>(n_threads, items);
+    if (nt <= 1) { worker(); return; }
+    std::vector<std::thread> th;
+    th.reserve(nt - 1);
+    for (int i = 1; i < nt; i++) th.emplace_back(worker);
+    worker();
+    for (auto &t : th) t.join();
+}
+
+// Synthetic stream: image i = LCG bytes, seed 0x9E3779B9 ^ i.
+void fill_synthetic(uint8_t *host, int W, int H, int C, int first_index, int n_images, int n_threads)
+{
+    if (n_images <= 0) return;
+    if (n_threads <= 0) n_threads = hardware_threads();
+    const size_t isz = (size_t)W * H * C;
+    std::atomic<int> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n_images) break;
+            uint32_t s = 0x9E3779B9u ^ (uint32_t)(first_index + i);
+            uint8_t *p = host + (size_t)i * isz;
+            for (size_t k = 0; k < isz; k++) {
+                s = s * 1664525u + 1013904223u;
+                p[k] = (uint8_t)(s >> 24);
+            }
+        }
+    };
+    const int nt = std::min(n_threads, n_images);
+    std::vector<std::thread> th;
+    for (int i = 1; i < nt; i++) th.emplace_back(worker);
+    worker();
+    for (auto &t : th) t.join();
+}
+
+uint64_t fnv1a64(const uint8_t *p, size_t n)
+{
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+
+}  // namespace mi_blur

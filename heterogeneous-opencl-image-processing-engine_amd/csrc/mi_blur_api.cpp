@@ -1,0 +1,695 @@
+// mi_blur_api.cpp — implementation of the C ABI declared in include/mi_blur.h.
+//
+// Each block names the reference OpenCL plumbing it replaces (paths relative to the
+// reference tree).  No torch, no OpenCL; HIP runtime + (lazily dlopen'ed) RCCL only.
+#include "../../include/mi_blur.h"
+#include "blur_launch.h"
+#include "cpu_device.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
+using namespace mi_blur;
+
+#define HIP_TRY(expr)                                                       \
+    do {                                                                    \
+        hipError_t e_ = (expr);                                             \
+        if (e_ != hipSuccess) { (void)hipGetLastError(); return MI_BLUR_ERR_HIP_BASE - (int)e_; } \
+    } while (0)
+
+// ----------------------------------------------------------------------------------
+// status / discovery   (replaces cl_error strings + heterogeneous_blur.c:142-184)
+// ----------------------------------------------------------------------------------
+extern "C" const char *mi_blur_strerror(int status)
+{
+    static thread_local char buf[160];
+    switch (status) {
+    case MI_BLUR_OK: return "success";
+    case MI_BLUR_ERR_INVALID: return "invalid argument";
+    case MI_BLUR_ERR_NO_DEVICE: return "no usable HIP device";
+    case MI_BLUR_ERR_NOMEM: return "out of memory";
+    case MI_BLUR_ERR_STATE: return "call not valid in this state";
+    case MI_BLUR_ERR_UNSUPPORTED: return "not supported in this build/environment";
+    }
+    if (status <= MI_BLUR_ERR_RCCL_BASE && status > MI_BLUR_ERR_RCCL_BASE - 100) {
+        snprintf(buf, sizeof buf, "RCCL error %d", MI_BLUR_ERR_RCCL_BASE - status);
+        return buf;
+    }
+    if (status <= MI_BLUR_ERR_HIP_BASE) {
+        const hipError_t e = (hipError_t)(MI_BLUR_ERR_HIP_BASE - status);
+        snprintf(buf, sizeof buf, "HIP error %d: %s", (int)e, hipGetErrorString(e));
+        return buf;
+    }
+    snprintf(buf, sizeof buf, "unknown status %d", status);
+    return buf;
+}
+
+extern "C" int mi_blur_version(void) { return MI_BLUR_VERSION; }
+
+extern "C" int mi_blur_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+extern "C" int mi_blur_set_option(const char *key, int value)
+{
+    if (!key) return MI_BLUR_ERR_INVALID;
+    Tunables &t = tunables();
+    if (!strcmp(key, "stage_dma")) t.stage_dma = value != 0;
+    else if (!strcmp(key, "rows_per_thread")) { if (value != 8 && value != 16) return MI_BLUR_ERR_INVALID; t.rpg = value; }
+    else if (!strcmp(key, "xcd_remap")) t.xcd_remap = value != 0;
+    else return MI_BLUR_ERR_INVALID;
+    return MI_BLUR_OK;
+}
+
+// ----------------------------------------------------------------------------------
+// kernel level   (clSetKernelArg x5 + clEnqueueNDRangeKernel)
+// ----------------------------------------------------------------------------------
+extern "C" int mi_blur_enqueue_ex(const uint8_t *d_in, uint8_t *d_out, int width, int band_rows, int channels,
+                                  int radius, int n_images, int out_row_begin, int out_row_end, int variant,
+                                  void *stream)
+{
+    if (mi_blur_device_count() <= 0) return MI_BLUR_ERR_NO_DEVICE;
+    LaunchDesc d{};
+    d.in = d_in; d.out = d_out; d.width = width; d.band_rows = band_rows; d.channels = channels;
+    d.radius = radius; d.n_images = n_images; d.y0 = out_row_begin; d.y1 = out_row_end;
+    d.variant = variant; d.stream = (hipStream_t)stream;
+    return launch(d);
+}
+
+extern "C" int mi_blur_enqueue(const uint8_t *d_in, uint8_t *d_out, int width, int height, int channels,
+                               int radius, int n_images, void *stream)
+{
+    return mi_blur_enqueue_ex(d_in, d_out, width, height, channels, radius, n_images, 0, height,
+                              MI_BLUR_VARIANT_AUTO, stream);
+}
+
+extern "C" int mi_blur_enqueue_band(const uint8_t *d_in, uint8_t *d_out, int width, int band_rows, int channels,
+                                    int radius, int out_row_begin, int out_row_end, void *stream)
+{
+    return mi_blur_enqueue_ex(d_in, d_out, width, band_rows, channels, radius, 1, out_row_begin, out_row_end,
+                              MI_BLUR_VARIANT_AUTO, stream);
+}
+
+// ----------------------------------------------------------------------------------
+// queue level
+// ----------------------------------------------------------------------------------
+namespace {
+
+struct Slot {
+    hipStream_t stream = nullptr;
+    uint8_t *h_in = nullptr, *h_out = nullptr;   // pinned staging (used when the caller's memory is pageable)
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // H2D begin/end, D2H begin/end
+    hipEvent_t ks = nullptr, ke = nullptr;                     // kernel dispatch start/stop
+    bool busy = false;
+    uint8_t *user_out = nullptr;
+    size_t in_bytes = 0, out_bytes = 0;
+    bool out_staged = false;
+};
+
+struct TimedLaunch { hipEvent_t s, e; };
+
+struct CpuJob {
+    std::thread th;
+    double ms = 0.0;
+};
+
+}  // namespace
+
+struct mi_blur_ctx {
+    int device = 0, W = 0, H = 0, C = 0, R = 1, max_batch = 0, n_threads = 0;
+    size_t image_bytes = 0;
+    std::vector<Slot> slots;
+    int next_slot = 0;
+    mi_blur_timing tm{};
+    // resident pool
+    uint8_t *pool_in = nullptr, *pool_out = nullptr;
+    int pool_images = 0;
+    long long cursor = 0;
+    int rr = 0;
+    std::vector<TimedLaunch> ev_pool;
+    size_t ev_used = 0;
+    // CPU device
+    std::vector<CpuJob *> cpu_jobs;
+    bool is_cpu() const { return device == MI_BLUR_DEVICE_CPU; }
+};
+
+static bool is_pinned(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+extern "C" void *mi_blur_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (mi_blur_device_count() > 0) {
+        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess) return p;
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return malloc(bytes);   // CPU-only operation: ordinary memory
+}
+
+extern "C" void mi_blur_host_free(void *p)
+{
+    if (!p) return;
+    if (mi_blur_device_count() > 0 && is_pinned(p)) { (void)hipHostFree(p); return; }
+    free(p);
+}
+
+static void free_slot(Slot &s)
+{
+    if (s.h_in) (void)hipHostFree(s.h_in);
+    if (s.h_out) (void)hipHostFree(s.h_out);
+    if (s.d_in) (void)hipFree(s.d_in);
+    if (s.d_out) (void)hipFree(s.d_out);
+    for (auto &e : s.ev) if (e) (void)hipEventDestroy(e);
+    if (s.ks) (void)hipEventDestroy(s.ks);
+    if (s.ke) (void)hipEventDestroy(s.ke);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+    s = Slot{};
+}
+
+// Context + queue + buffers: heterogeneous_blur.c:194-212 (contexts, profiling queues),
+// :341-354 (one in + one out buffer per device).  Here: n_slots streams, each with a
+// max_batch-image device buffer pair, so one launch covers a whole batch.
+extern "C" int mi_blur_create(mi_blur_ctx **out_ctx, int device, int width, int height, int channels, int radius,
+                              int max_batch, int n_slots, int n_threads)
+{
+    if (!out_ctx) return MI_BLUR_ERR_INVALID;
+    *out_ctx = nullptr;
+    if (width <= 0 || height <= 0 || channels <= 0 || max_batch <= 0 || n_slots <= 0) return MI_BLUR_ERR_INVALID;
+    if (radius != 1 && radius != 2) return MI_BLUR_ERR_INVALID;
+    if ((long long)width * channels * height > 0x7fffffffLL) return MI_BLUR_ERR_INVALID;
+    mi_blur_ctx *c = new (std::nothrow) mi_blur_ctx;
+    if (!c) return MI_BLUR_ERR_NOMEM;
+    c->device = device; c->W = width; c->H = height; c->C = channels; c->R = radius;
+    c->max_batch = max_batch;
+    c->n_threads = n_threads > 0 ? n_threads : hardware_threads();
+    c->image_bytes = (size_t)width * height * channels;
+    if (device == MI_BLUR_DEVICE_CPU) { *out_ctx = c; return MI_BLUR_OK; }
+
+    const int ndev = mi_blur_device_count();
+    if (ndev <= 0 || device < 0 || device >= ndev) { delete c; return MI_BLUR_ERR_NO_DEVICE; }
+    int rc = MI_BLUR_OK;
+    auto fail = [&](hipError_t e) { (void)hipGetLastError(); rc = MI_BLUR_ERR_HIP_BASE - (int)e; return true; };
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) { fail(e); delete c; return rc; }
+    const size_t bytes = c->image_bytes * (size_t)max_batch;
+    c->slots.resize(n_slots);
+    for (auto &s : c->slots) {
+        if ((e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking)) != hipSuccess && fail(e)) break;
+        if ((e = hipHostMalloc((void **)&s.h_in, bytes, hipHostMallocDefault)) != hipSuccess && fail(e)) break;
+        if ((e = hipHostMalloc((void **)&s.h_out, bytes, hipHostMallocDefault)) != hipSuccess && fail(e)) break;
+        if ((e = hipMalloc((void **)&s.d_in, bytes)) != hipSuccess && fail(e)) break;
+        if ((e = hipMalloc((void **)&s.d_out, bytes)) != hipSuccess && fail(e)) break;
+        for (auto &ev : s.ev) if ((e = hipEventCreate(&ev)) != hipSuccess && fail(e)) break;
+        if (rc) break;
+        if ((e = hipEventCreate(&s.ks)) != hipSuccess && fail(e)) break;
+        if ((e = hipEventCreate(&s.ke)) != hipSuccess && fail(e)) break;
+    }
+    if (rc) { mi_blur_destroy(c); return rc; }
+    *out_ctx = c;
+    return MI_BLUR_OK;
+}
+
+static int finish_slot(mi_blur_ctx *c, Slot &s)
+{
+    if (!s.busy) return MI_BLUR_OK;
+    HIP_TRY(hipStreamSynchronize(s.stream));
+    if (s.out_staged) memcpy(s.user_out, s.h_out, s.out_bytes);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) c->tm.h2d_ms += ms;
+    if (hipEventElapsedTime(&ms, s.ks, s.ke) == hipSuccess) c->tm.kernel_ms += ms;
+    if (hipEventElapsedTime(&ms, s.ev[2], s.ev[3]) == hipSuccess) c->tm.d2h_ms += ms;
+    (void)hipGetLastError();
+    s.busy = false;
+    return MI_BLUR_OK;
+}
+
+static int harvest_resident(mi_blur_ctx *c)
+{
+    for (size_t i = 0; i < c->ev_used; i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev_pool[i].s, c->ev_pool[i].e) == hipSuccess) c->tm.kernel_ms += ms;
+    }
+    (void)hipGetLastError();
+    c->ev_used = 0;
+    return MI_BLUR_OK;
+}
+
+// clFinish + clGetEventProfilingInfo harvest (heterogeneous_blur.c:538-579).
+extern "C" int mi_blur_sync(mi_blur_ctx *c, mi_blur_timing *timing)
+{
+    if (!c) return MI_BLUR_ERR_INVALID;
+    if (c->is_cpu()) {
+        for (CpuJob *j : c->cpu_jobs) {
+            j->th.join();
+            c->tm.kernel_ms += j->ms;
+            delete j;
+        }
+        c->cpu_jobs.clear();
+    } else {
+        HIP_TRY(hipSetDevice(c->device));
+        for (auto &s : c->slots) {
+            int rc = finish_slot(c, s);
+            if (rc) return rc;
+        }
+        for (auto &s : c->slots) HIP_TRY(hipStreamSynchronize(s.stream));
+        harvest_resident(c);
+    }
+    if (timing) *timing = c->tm;
+    return MI_BLUR_OK;
+}
+
+extern "C" void mi_blur_reset_timing(mi_blur_ctx *c)
+{
+    if (c) c->tm = mi_blur_timing{};
+}
+
+// Cleanup: heterogeneous_blur.c:727-744.
+extern "C" void mi_blur_destroy(mi_blur_ctx *c)
+{
+    if (!c) return;
+    for (CpuJob *j : c->cpu_jobs) { j->th.join(); delete j; }
+    if (!c->is_cpu()) {
+        (void)hipSetDevice(c->device);
+        for (auto &s : c->slots) { if (s.stream) (void)hipStreamSynchronize(s.stream); }
+        for (auto &s : c->slots) free_slot(s);
+        for (auto &t : c->ev_pool) { (void)hipEventDestroy(t.s); (void)hipEventDestroy(t.e); }
+        if (c->pool_in) (void)hipFree(c->pool_in);
+        if (c->pool_out) (void)hipFree(c->pool_out);
+        (void)hipGetLastError();
+    }
+    delete c;
+}
+
+// One band/batch through a slot: Write -> NDRange -> Read (heterogeneous_blur.c:520-533),
+// but one launch for the whole batch instead of one per image.
+static int submit_common(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_out, int band_rows, int n_images,
+                         int y0, int y1)
+{
+    const size_t pitch = (size_t)c->W * c->C;
+    const size_t in_bytes = pitch * band_rows * n_images, out_bytes = pitch * (size_t)(y1 - y0) * n_images;
+    if (c->is_cpu()) {
+        CpuJob *j = new (std::nothrow) CpuJob;
+        if (!j) return MI_BLUR_ERR_NOMEM;
+        const int W = c->W, C = c->C, R = c->R, nt = c->n_threads;
+        j->th = std::thread([=]() {
+            const auto t0 = std::chrono::steady_clock::now();
+            cpu_blur_batch(host_in, host_out, W, band_rows, C, R, n_images, y0, y1, nt);
+            j->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        });
+        c->cpu_jobs.push_back(j);
+    } else {
+        HIP_TRY(hipSetDevice(c->device));
+        Slot &s = c->slots[c->next_slot];
+        c->next_slot = (c->next_slot + 1) % (int)c->slots.size();
+        int rc = finish_slot(c, s);
+        if (rc) return rc;
+        const uint8_t *src = host_in;
+        if (!is_pinned(host_in)) { memcpy(s.h_in, host_in, in_bytes); src = s.h_in; }
+        s.out_staged = !is_pinned(host_out);
+        s.user_out = host_out; s.in_bytes = in_bytes; s.out_bytes = out_bytes;
+        HIP_TRY(hipEventRecord(s.ev[0], s.stream));
+        HIP_TRY(hipMemcpyAsync(s.d_in, src, in_bytes, hipMemcpyHostToDevice, s.stream));
+        HIP_TRY(hipEventRecord(s.ev[1], s.stream));
+        LaunchDesc d{};
+        d.in = s.d_in; d.out = s.d_out; d.width = c->W; d.band_rows = band_rows; d.channels = c->C;
+        d.radius = c->R; d.n_images = n_images; d.y0 = y0; d.y1 = y1; d.variant = MI_BLUR_VARIANT_AUTO;
+        d.stream = s.stream; d.start = s.ks; d.stop = s.ke;
+        rc = launch(d);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(s.ev[2], s.stream));
+        HIP_TRY(hipMemcpyAsync(s.out_staged ? s.h_out : host_out, s.d_out, out_bytes, hipMemcpyDeviceToHost, s.stream));
+        HIP_TRY(hipEventRecord(s.ev[3], s.stream));
+        s.busy = true;
+        c->tm.bytes_h2d += in_bytes; c->tm.bytes_d2h += out_bytes;
+    }
+    c->tm.bytes_alg += 2ull * out_bytes;
+    c->tm.images += (uint64_t)n_images;
+    c->tm.launches += 1;
+    return MI_BLUR_OK;
+}
+
+extern "C" int mi_blur_submit(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_out, int n_images)
+{
+    if (!c || !host_in || !host_out || host_in == host_out) return MI_BLUR_ERR_INVALID;
+    if (n_images < 0 || n_images > c->max_batch) return MI_BLUR_ERR_INVALID;
+    if (n_images == 0) return MI_BLUR_OK;
+    return submit_common(c, host_in, host_out, c->H, n_images, 0, c->H);
+}
+
+extern "C" int mi_blur_submit_band(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_out, int band_rows,
+                                   int halo_top, int halo_bottom)
+{
+    if (!c || !host_in || !host_out || host_in == host_out) return MI_BLUR_ERR_INVALID;
+    if (band_rows <= 0 || band_rows > c->H || halo_top < 0 || halo_bottom < 0) return MI_BLUR_ERR_INVALID;
+    if (halo_top + halo_bottom >= band_rows) return MI_BLUR_ERR_INVALID;
+    return submit_common(c, host_in, host_out, band_rows, 1, halo_top, band_rows - halo_bottom);
+}
+
+// ----------------------------------------------------------------------------------
+// device-resident stream
+// ----------------------------------------------------------------------------------
+extern "C" int mi_blur_resident_alloc(mi_blur_ctx *c, int pool_images)
+{
+    if (!c || pool_images <= 0) return MI_BLUR_ERR_INVALID;
+    if (c->is_cpu()) return MI_BLUR_ERR_STATE;
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->pool_in) { (void)hipFree(c->pool_in); c->pool_in = nullptr; }
+    if (c->pool_out) { (void)hipFree(c->pool_out); c->pool_out = nullptr; }
+    c->pool_images = 0; c->cursor = 0;
+    const size_t bytes = c->image_bytes * (size_t)pool_images;
+    HIP_TRY(hipMalloc((void **)&c->pool_in, bytes));
+    HIP_TRY(hipMalloc((void **)&c->pool_out, bytes));
+    c->pool_images = pool_images;
+    return MI_BLUR_OK;
+}
+
+extern "C" int mi_blur_resident_upload(mi_blur_ctx *c, int pool_index, const uint8_t *host_in, int n_images)
+{
+    if (!c || !host_in || !c->pool_in) return MI_BLUR_ERR_STATE;
+    if (pool_index < 0 || n_images < 0 || pool_index + n_images > c->pool_images) return MI_BLUR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpy(c->pool_in + (size_t)pool_index * c->image_bytes, host_in, c->image_bytes * (size_t)n_images,
+                      hipMemcpyHostToDevice));
+    return MI_BLUR_OK;
+}
+
+extern "C" int mi_blur_resident_download(mi_blur_ctx *c, int pool_index, uint8_t *host_out, int n_images)
+{
+    if (!c || !host_out || !c->pool_out) return MI_BLUR_ERR_STATE;
+    if (pool_index < 0 || n_images < 0 || pool_index + n_images > c->pool_images) return MI_BLUR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host_out, c->pool_out + (size_t)pool_index * c->image_bytes, c->image_bytes * (size_t)n_images,
+                      hipMemcpyDeviceToHost));
+    return MI_BLUR_OK;
+}
+
+extern "C" int mi_blur_resident_fill_synthetic(mi_blur_ctx *c, int first_index)
+{
+    if (!c || !c->pool_in) return MI_BLUR_ERR_STATE;
+    const int chunk = std::max(1, (int)std::min<size_t>((size_t)c->pool_images, ((size_t)256 << 20) / c->image_bytes));
+    std::vector<uint8_t> host;
+    try { host.resize(c->image_bytes * (size_t)chunk); } catch (...) { return MI_BLUR_ERR_NOMEM; }
+    for (int i = 0; i < c->pool_images; i += chunk) {
+        const int n = std::min(chunk, c->pool_images - i);
+        fill_synthetic(host.data(), c->W, c->H, c->C, first_index + i, n, c->n_threads);
+        int rc = mi_blur_resident_upload(c, i, host.data(), n);
+        if (rc) return rc;
+    }
+    return MI_BLUR_OK;
+}
+
+extern "C" void *mi_blur_resident_in(mi_blur_ctx *c) { return c ? c->pool_in : nullptr; }
+extern "C" void *mi_blur_resident_out(mi_blur_ctx *c) { return c ? c->pool_out : nullptr; }
+
+// One pass of the stream over the resident pool: the batch loop of
+// heterogeneous_blur.c:418-427 with the transfers gone (data already in HBM).
+extern "C" int mi_blur_resident_run(mi_blur_ctx *c, int n_images, int batch, int timed)
+{
+    if (!c || n_images < 0 || batch <= 0) return MI_BLUR_ERR_INVALID;
+    if (c->is_cpu() || !c->pool_in) return MI_BLUR_ERR_STATE;
+    if (batch > c->pool_images) return MI_BLUR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    for (int done = 0; done < n_images; done += batch) {
+        const int b = std::min(batch, n_images - done);
+        if (c->cursor + b > c->pool_images) c->cursor = 0;
+        Slot &s = c->slots[c->rr];
+        c->rr = (c->rr + 1) % (int)c->slots.size();
+        LaunchDesc d{};
+        d.in = c->pool_in + (size_t)c->cursor * c->image_bytes;
+        d.out = c->pool_out + (size_t)c->cursor * c->image_bytes;
+        d.width = c->W; d.band_rows = c->H; d.channels = c->C; d.radius = c->R; d.n_images = b;
+        d.y0 = 0; d.y1 = c->H; d.variant = MI_BLUR_VARIANT_AUTO; d.stream = s.stream;
+        if (timed) {
+            if (c->ev_used == c->ev_pool.size()) {
+                TimedLaunch t{};
+                HIP_TRY(hipEventCreate(&t.s));
+                HIP_TRY(hipEventCreate(&t.e));
+                c->ev_pool.push_back(t);
+            }
+            d.start = c->ev_pool[c->ev_used].s; d.stop = c->ev_pool[c->ev_used].e;
+            c->ev_used++;
+        }
+        int rc = launch(d);
+        if (rc) return rc;
+        c->cursor += b;
+        c->tm.launches += 1;
+    }
+    c->tm.images += (uint64_t)n_images;
+    c->tm.bytes_alg += 2ull * c->image_bytes * (uint64_t)n_images;
+    return MI_BLUR_OK;
+}
+
+// ----------------------------------------------------------------------------------
+// CPU device kernel + helpers
+// ----------------------------------------------------------------------------------
+extern "C" int mi_blur_cpu_run(const uint8_t *in, uint8_t *out, int width, int height, int channels, int radius,
+                               int n_images, int n_threads)
+{
+    if (!in || !out || in == out || width <= 0 || height <= 0 || channels <= 0 || n_images < 0)
+        return MI_BLUR_ERR_INVALID;
+    if (radius != 1 && radius != 2) return MI_BLUR_ERR_INVALID;
+    cpu_blur_batch(in, out, width, height, channels, radius, n_images, 0, height, n_threads);
+    return MI_BLUR_OK;
+}
+
+extern "C" void mi_blur_fill_synthetic(uint8_t *host, int width, int height, int channels, int first_index,
+                                       int n_images, int n_threads)
+{
+    if (host && width > 0 && height > 0 && channels > 0)
+        fill_synthetic(host, width, height, channels, first_index, n_images, n_threads);
+}
+
+extern "C" uint64_t mi_blur_fnv1a64(const uint8_t *host, size_t n) { return fnv1a64(host, n); }
+
+// heterogeneous_blur.c:449-458 — evaluated in float exactly as there.
+extern "C" void mi_blur_a1_partition(int mode, int batch_count, float gpu_ratio, int *n_cpu, int *n_gpu)
+{
+    int nc, ng;
+    if (mode == 0) { ng = (int)(batch_count * gpu_ratio); nc = batch_count - ng; }
+    else if (mode == 1) { nc = batch_count; ng = 0; }
+    else { nc = 0; ng = batch_count; }
+    if (n_cpu) *n_cpu = nc;
+    if (n_gpu) *n_gpu = ng;
+}
+
+extern "C" void mi_blur_shard_range(long long n_units, int g, int G, long long *begin, long long *end)
+{
+    if (G <= 0) G = 1;
+    if (begin) *begin = n_units * g / G;
+    if (end) *end = n_units * (g + 1) / G;
+}
+
+// split_image_blur.c:144-166.
+extern "C" void mi_blur_a2_split(int height, float gpu_ratio, int halo, mi_blur_a2_geometry *g)
+{
+    if (!g) return;
+    int split_row = (int)(height * (1.0f - gpu_ratio));
+    if (split_row < halo) split_row = halo;
+    if (split_row > height - halo) split_row = height - halo;
+    g->split_row = split_row;
+    g->cpu_input_rows = split_row + halo;
+    g->cpu_output_rows = split_row;
+    g->gpu_input_rows = (height - split_row) + halo;
+    g->gpu_output_rows = height - split_row;
+}
+
+extern "C" void mi_blur_band_of(int height, int radius, int g, int G, mi_blur_band *b)
+{
+    if (!b) return;
+    if (G <= 0) G = 1;
+    b->row_begin = (int)((long long)height * g / G);
+    b->row_end = (int)((long long)height * (g + 1) / G);
+    b->halo_top = std::min(radius, b->row_begin);
+    b->halo_bottom = std::min(radius, height - b->row_end);
+}
+
+// ----------------------------------------------------------------------------------
+// RCCL halo exchange (Approach 2 on resident row shards)
+// ----------------------------------------------------------------------------------
+namespace {
+
+struct Rccl {
+    void *h = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    bool ok = false;
+};
+
+Rccl &rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            r.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.h) break;
+        }
+        if (!r.h) return;
+#define MI_SYM(field, sym) r.field = (decltype(r.field))dlsym(r.h, #sym)
+        MI_SYM(GetUniqueId, ncclGetUniqueId);
+        MI_SYM(CommInitRank, ncclCommInitRank);
+        MI_SYM(CommInitAll, ncclCommInitAll);
+        MI_SYM(CommDestroy, ncclCommDestroy);
+        MI_SYM(Send, ncclSend);
+        MI_SYM(Recv, ncclRecv);
+        MI_SYM(GroupStart, ncclGroupStart);
+        MI_SYM(GroupEnd, ncclGroupEnd);
+#undef MI_SYM
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.Send && r.Recv &&
+               r.GroupStart && r.GroupEnd;
+    });
+    return r;
+}
+
+inline int nccl_status(ncclResult_t e) { return e == ncclSuccess ? MI_BLUR_OK : MI_BLUR_ERR_RCCL_BASE - (int)e; }
+
+}  // namespace
+
+struct mi_blur_comm {
+    ncclComm_t comm = nullptr;
+    int n_ranks = 1, rank = 0, device = -1;
+};
+
+static_assert(sizeof(ncclUniqueId) == MI_BLUR_UNIQUE_ID_BYTES, "ncclUniqueId size");
+
+extern "C" int mi_blur_comm_unique_id(uint8_t id[MI_BLUR_UNIQUE_ID_BYTES])
+{
+    if (!id) return MI_BLUR_ERR_INVALID;
+    Rccl &r = rccl();
+    if (!r.ok) return MI_BLUR_ERR_UNSUPPORTED;
+    ncclUniqueId u;
+    int rc = nccl_status(r.GetUniqueId(&u));
+    if (rc) return rc;
+    memcpy(id, &u, sizeof u);
+    return MI_BLUR_OK;
+}
+
+extern "C" int mi_blur_comm_init_rank(mi_blur_comm **comm, int n_ranks, int rank,
+                                      const uint8_t id[MI_BLUR_UNIQUE_ID_BYTES])
+{
+    if (!comm || !id || n_ranks <= 0 || rank < 0 || rank >= n_ranks) return MI_BLUR_ERR_INVALID;
+    *comm = nullptr;
+    mi_blur_comm *c = new (std::nothrow) mi_blur_comm;
+    if (!c) return MI_BLUR_ERR_NOMEM;
+    c->n_ranks = n_ranks; c->rank = rank;
+    if (hipGetDevice(&c->device) != hipSuccess) { (void)hipGetLastError(); delete c; return MI_BLUR_ERR_NO_DEVICE; }
+    if (n_ranks > 1) {
+        Rccl &r = rccl();
+        if (!r.ok) { delete c; return MI_BLUR_ERR_UNSUPPORTED; }
+        ncclUniqueId u;
+        memcpy(&u, id, sizeof u);
+        int rc = nccl_status(r.CommInitRank(&c->comm, n_ranks, u, rank));
+        if (rc) { delete c; return rc; }
+    }
+    *comm = c;
+    return MI_BLUR_OK;
+}
+
+extern "C" int mi_blur_comm_init_all(mi_blur_comm **comms, int n_devices, const int *devices)
+{
+    if (!comms || n_devices <= 0) return MI_BLUR_ERR_INVALID;
+    std::vector<ncclComm_t> raw(n_devices, nullptr);
+    std::vector<int> devs(n_devices);
+    for (int i = 0; i < n_devices; i++) devs[i] = devices ? devices[i] : i;
+    if (n_devices > 1) {
+        Rccl &r = rccl();
+        if (!r.ok) return MI_BLUR_ERR_UNSUPPORTED;
+        int rc = nccl_status(r.CommInitAll(raw.data(), n_devices, devs.data()));
+        if (rc) return rc;
+    }
+    for (int i = 0; i < n_devices; i++) {
+        mi_blur_comm *c = new (std::nothrow) mi_blur_comm;
+        if (!c) return MI_BLUR_ERR_NOMEM;
+        c->comm = raw[i]; c->n_ranks = n_devices; c->rank = i; c->device = devs[i];
+        comms[i] = c;
+    }
+    return MI_BLUR_OK;
+}
+
+extern "C" void mi_blur_comm_destroy(mi_blur_comm *c)
+{
+    if (!c) return;
+    if (c->comm) (void)rccl().CommDestroy(c->comm);
+    delete c;
+}
+
+static int halo_exchange_calls(Rccl &r, mi_blur_comm *c, uint8_t *d_band, size_t pitch, int owned_rows, int radius,
+                               hipStream_t stream)
+{
+    const int top = c->rank > 0 ? radius : 0;
+    const size_t n = pitch * (size_t)radius;
+    ncclResult_t e = ncclSuccess;
+    if (c->rank > 0) {
+        if ((e = r.Send(d_band + (size_t)top * pitch, n, ncclUint8, c->rank - 1, c->comm, stream)) != ncclSuccess) return nccl_status(e);
+        if ((e = r.Recv(d_band, n, ncclUint8, c->rank - 1, c->comm, stream)) != ncclSuccess) return nccl_status(e);
+    }
+    if (c->rank < c->n_ranks - 1) {
+        uint8_t *last = d_band + (size_t)(top + owned_rows - radius) * pitch;
+        if ((e = r.Send(last, n, ncclUint8, c->rank + 1, c->comm, stream)) != ncclSuccess) return nccl_status(e);
+        if ((e = r.Recv(d_band + (size_t)(top + owned_rows) * pitch, n, ncclUint8, c->rank + 1, c->comm, stream)) != ncclSuccess) return nccl_status(e);
+    }
+    return MI_BLUR_OK;
+}
+
+extern "C" int mi_blur_halo_exchange(mi_blur_comm *c, uint8_t *d_band, int width, int channels, int owned_rows,
+                                     int radius, void *stream)
+{
+    if (!c || !d_band || width <= 0 || channels <= 0 || radius < 1 || owned_rows < radius) return MI_BLUR_ERR_INVALID;
+    if (c->n_ranks == 1) return MI_BLUR_OK;            // nothing to exchange: both edges clamp
+    Rccl &r = rccl();
+    if (!r.ok || !c->comm) return MI_BLUR_ERR_UNSUPPORTED;
+    int rc = nccl_status(r.GroupStart());
+    if (rc) return rc;
+    rc = halo_exchange_calls(r, c, d_band, (size_t)width * channels, owned_rows, radius, (hipStream_t)stream);
+    int rc2 = nccl_status(r.GroupEnd());
+    return rc ? rc : rc2;
+}
+
+// All ranks of a single-process communicator set in ONE RCCL group (one host thread
+// driving G GPUs must not block on rank 0's group before enqueuing rank 1's).
+extern "C" int mi_blur_halo_exchange_all(mi_blur_comm **comms, int n, uint8_t **d_bands, int width, int channels,
+                                         const int *owned_rows, int radius, void **streams)
+{
+    if (!comms || !d_bands || !owned_rows || n <= 0) return MI_BLUR_ERR_INVALID;
+    if (n == 1) return MI_BLUR_OK;
+    Rccl &r = rccl();
+    if (!r.ok) return MI_BLUR_ERR_UNSUPPORTED;
+    int rc = nccl_status(r.GroupStart());
+    if (rc) return rc;
+    for (int i = 0; i < n && !rc; i++) {
+        if (owned_rows[i] < radius) { rc = MI_BLUR_ERR_INVALID; break; }
+        if (hipSetDevice(comms[i]->device) != hipSuccess) { (void)hipGetLastError(); rc = MI_BLUR_ERR_NO_DEVICE; break; }
+        rc = halo_exchange_calls(r, comms[i], d_bands[i], (size_t)width * channels, owned_rows[i], radius,
+                                 streams ? (hipStream_t)streams[i] : nullptr);
+    }
+    int rc2 = nccl_status(r.GroupEnd());
+    return rc ? rc : rc2;
+}

@@ -1,0 +1,233 @@
+/*
+ * mi_blur.h — C ABI of the MI355X-native image-stream blur engine (libmi_blur.so).
+ *
+ * The reference (CC834/Heterogeneous-OpenCL-Image-Processing-Engine) has no
+ * plugin/FFI surface: its hot path sits behind the OpenCL C API called from two
+ * main() functions.  Each entry point below replaces one group of those OpenCL
+ * calls; the citation is the reference call site it stands in for (paths are
+ * relative to the reference tree).  INTEGRATION.md shows the edit a maintainer
+ * makes in heterogeneous_blur.c / split_image_blur.c to bind them.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types; every function returns
+ *     MI_BLUR_OK (0) or a negative mi_blur_status / positive passthrough code
+ *     (see mi_blur_strerror).  The library never calls exit(): the reference's
+ *     cl_error() print-and-exit policy (heterogeneous_blur.c:25-30) stays in the host.
+ *   - images are interleaved uint8, row-major, pitch = width*channels, no padding
+ *     (gaussian_kernel.cl:60; heterogeneous_blur.c:115,128-135); in != out.
+ *   - radius 1 = the reference 3x3 {1,2,1}x{1,2,1}/16 (gaussian_kernel.cl:36-41);
+ *     radius 2 = build-defined 5x5 {1,4,6,4,1}x{1,4,6,4,1}/256 (no reference kernel).
+ *     Clamp-to-edge (:56-57), truncation (:70).
+ *   - a context is single-threaded like a cl_command_queue used from one thread;
+ *     different contexts may be driven from different host threads.
+ *   - GPU entry points fail with MI_BLUR_ERR_NO_DEVICE when no HIP device is
+ *     usable.  There is NO silent CPU fallback: the CPU device exists only when
+ *     asked for by name (MI_BLUR_DEVICE_CPU), mirroring the reference's separate
+ *     OpenCL CPU device (heterogeneous_blur.c:170-176).
+ */
+#ifndef MI_BLUR_H
+#define MI_BLUR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_BLUR_VERSION 1
+#define MI_BLUR_DEVICE_CPU (-1)      /* native host-thread device (reference: CL_DEVICE_TYPE_CPU) */
+
+typedef enum mi_blur_status {
+    MI_BLUR_OK = 0,
+    MI_BLUR_ERR_INVALID = -1,        /* bad argument (null, non-positive size, radius not 1|2, in==out) */
+    MI_BLUR_ERR_NO_DEVICE = -2,      /* no usable HIP device / device index out of range */
+    MI_BLUR_ERR_NOMEM = -3,          /* host or device allocation failed */
+    MI_BLUR_ERR_STATE = -4,          /* call not valid in the context's current state */
+    MI_BLUR_ERR_UNSUPPORTED = -5,    /* e.g. RCCL entry point in a build without RCCL */
+    MI_BLUR_ERR_HIP_BASE = -1000,    /* -(1000 + hipError_t) */
+    MI_BLUR_ERR_RCCL_BASE = -2000    /* -(2000 + ncclResult_t) */
+} mi_blur_status;
+
+/* Kernel variant selector for mi_blur_enqueue_ex (tests force each path). */
+typedef enum mi_blur_variant {
+    MI_BLUR_VARIANT_AUTO = 0,        /* LDS-tiled vector kernel when pitch%16==0 && channels<=4, else generic */
+    MI_BLUR_VARIANT_GENERIC = 1,     /* one output byte per thread, any shape */
+    MI_BLUR_VARIANT_TILED = 2        /* LDS halo tile + 16-B vector loads (fails with _INVALID if ineligible) */
+} mi_blur_variant;
+
+const char *mi_blur_strerror(int status);
+int mi_blur_version(void);
+
+/* Kernel tuning knobs (A/B benching and tests; defaults are the shipped configuration):
+ *   "stage_dma"        1 = stage LDS tiles with global_load_lds (default), 0 = through VGPRs
+ *   "rows_per_thread"  8 (default) | 16 output rows per thread of the tiled kernel
+ *   "xcd_remap"        1 = XCD-contiguous blockIdx->tile map (default), 0 = identity */
+int mi_blur_set_option(const char *key, int value);
+
+/* Number of visible HIP devices (0 is a valid answer: CPU-device contexts still work).
+ * Replaces the platform/device scan, heterogeneous_blur.c:142-184. */
+int mi_blur_device_count(void);
+
+/* ------------------------------------------------------------------------
+ * Kernel level — replaces clSetKernelArg x5 + clEnqueueNDRangeKernel
+ * (heterogeneous_blur.c:380-389,525; split_image_blur.c:407-418,533).
+ *
+ * d_in/d_out are DEVICE pointers on the current HIP device, n_images images laid
+ * end to end (image stride = width*height*channels).  One launch blurs the whole
+ * batch.  `stream` is a hipStream_t (NULL = default stream).  Asynchronous.
+ * ---------------------------------------------------------------------- */
+int mi_blur_enqueue(const uint8_t *d_in, uint8_t *d_out, int width, int height, int channels,
+                    int radius, int n_images, void *stream);
+
+/* Band form (Approach 2, split_image_blur.c:401,414,511-541): the input is a
+ * band of `band_rows` rows (clamping happens at the band's own first/last row,
+ * exactly as when the reference passes the sub-buffer height as `height`);
+ * only output rows [out_row_begin, out_row_end) of the band are produced and
+ * are written to d_out starting at d_out[0] (the halo rows the reference
+ * computes and then drops at read-back, :526,537, are never computed). */
+int mi_blur_enqueue_band(const uint8_t *d_in, uint8_t *d_out, int width, int band_rows, int channels,
+                         int radius, int out_row_begin, int out_row_end, void *stream);
+
+/* Full-control form used by the tests: variant selection; n_images bands. */
+int mi_blur_enqueue_ex(const uint8_t *d_in, uint8_t *d_out, int width, int band_rows, int channels,
+                       int radius, int n_images, int out_row_begin, int out_row_end,
+                       int variant, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Queue level — one context = one device + its in-order stream(s), pinned
+ * staging slots, device buffers and event timing.  Replaces context/queue/
+ * buffer creation (heterogeneous_blur.c:194-212,341-354), the per-image
+ * Write/NDRange/Read triple (:502-533), clFinish (:538-539) and the event
+ * bookkeeping (:544-579).
+ * ---------------------------------------------------------------------- */
+typedef struct mi_blur_ctx mi_blur_ctx;
+
+typedef struct mi_blur_timing {      /* cumulative since create / last reset; mirrors :411-412 */
+    double h2d_ms;                   /* transfer IN  (time_*_transfer_in)  */
+    double kernel_ms;                /* kernel       (time_*_kernel)       */
+    double d2h_ms;                   /* transfer OUT (time_*_transfer_out) */
+    uint64_t bytes_h2d, bytes_d2h;
+    uint64_t bytes_alg;              /* algorithmic bytes = 2*W*rows*C per image processed */
+    uint64_t images;
+    uint64_t launches;
+} mi_blur_timing;
+
+/* device: HIP ordinal, or MI_BLUR_DEVICE_CPU (n_threads host threads; 0 = all cores).
+ * max_batch: largest n_images of one submit.  n_slots: staging slots (>=1; 2-3 lets
+ * H2D(n+1), kernel(n) and D2H(n-1) overlap).  Each slot owns a pinned in/out pair,
+ * a device in/out pair and one stream. */
+int mi_blur_create(mi_blur_ctx **out_ctx, int device, int width, int height, int channels,
+                   int radius, int max_batch, int n_slots, int n_threads);
+void mi_blur_destroy(mi_blur_ctx *ctx);
+
+/* Page-locked host memory for stream buffers.  submit() DMA-copies straight from/to
+ * memory obtained here; ordinary (pageable) caller memory is accepted too and goes
+ * through the slot's own pinned staging buffers (one extra host memcpy each way). */
+void *mi_blur_host_alloc(size_t bytes);
+void mi_blur_host_free(void *p);
+
+/* Asynchronous H2D -> ONE batched launch -> D2H of n_images images from caller
+ * memory.  host_in/host_out must stay valid until mi_blur_sync (the reference
+ * frees batch_input/batch_output only after clFinish, heterogeneous_blur.c:538,596-597).
+ * Blocks only when every slot is still in flight. */
+int mi_blur_submit(mi_blur_ctx *ctx, const uint8_t *host_in, uint8_t *host_out, int n_images);
+
+/* Approach 2: host_in points at the first row of a band of band_rows rows that
+ * already includes halo_top/halo_bottom halo rows; host_out receives the
+ * band_rows-halo_top-halo_bottom interior rows (split_image_blur.c:511-541).
+ * band_rows may differ per call but must be <= the context's height. */
+int mi_blur_submit_band(mi_blur_ctx *ctx, const uint8_t *host_in, uint8_t *host_out,
+                        int band_rows, int halo_top, int halo_bottom);
+
+/* clFinish + event harvest (heterogeneous_blur.c:538-579).  timing may be NULL. */
+int mi_blur_sync(mi_blur_ctx *ctx, mi_blur_timing *timing);
+void mi_blur_reset_timing(mi_blur_ctx *ctx);
+
+/* ------------------------------------------------------------------------
+ * Device-resident stream (no reference analogue: the reference re-uploads
+ * every image).  The pool holds pool_images images in HBM (in + out).
+ * ---------------------------------------------------------------------- */
+int mi_blur_resident_alloc(mi_blur_ctx *ctx, int pool_images);
+/* Fill pool image i with the synthetic LCG image (seed 0x9E3779B9 ^ (first_index+i)). */
+int mi_blur_resident_fill_synthetic(mi_blur_ctx *ctx, int first_index);
+int mi_blur_resident_upload(mi_blur_ctx *ctx, int pool_index, const uint8_t *host_in, int n_images);
+int mi_blur_resident_download(mi_blur_ctx *ctx, int pool_index, uint8_t *host_out, int n_images);
+void *mi_blur_resident_in(mi_blur_ctx *ctx);       /* device pointers of the pool */
+void *mi_blur_resident_out(mi_blur_ctx *ctx);
+
+/* One pass of the image stream over the resident pool: n_images images taken
+ * cyclically from the pool, one launch per `batch` images (the last launch takes
+ * the remainder, heterogeneous_blur.c:423-427).  Launches go round-robin over the
+ * context's streams.  Kernel durations are taken per launch from the dispatch's
+ * own start/stop timestamps (the HIP analogue of clGetEventProfilingInfo) when
+ * timed != 0, and accumulate into the context's timing.  Asynchronous; follow
+ * with mi_blur_sync. */
+int mi_blur_resident_run(mi_blur_ctx *ctx, int n_images, int batch, int timed);
+
+/* ------------------------------------------------------------------------
+ * CPU device kernel, exposed for the hosts' `cpu` mode and for timing the
+ * host-core path beside the GPU (BASELINE.json config 0).  Scalar per-pixel
+ * integer form of gaussian_kernel.cl:19-72, n_threads host threads over images
+ * (over row bands when n_images < n_threads).  Synchronous.
+ * ---------------------------------------------------------------------- */
+int mi_blur_cpu_run(const uint8_t *in, uint8_t *out, int width, int height, int channels,
+                    int radius, int n_images, int n_threads);
+
+/* Synthetic stream generator shared by hosts, bench and tests. */
+void mi_blur_fill_synthetic(uint8_t *host, int width, int height, int channels,
+                            int first_index, int n_images, int n_threads);
+uint64_t mi_blur_fnv1a64(const uint8_t *host, size_t n);
+
+/* ------------------------------------------------------------------------
+ * Work distribution helpers — host logic of the two approaches.
+ * ---------------------------------------------------------------------- */
+/* Approach 1, heterogeneous_blur.c:449-458: mode 0 both / 1 cpu / 2 gpu. */
+void mi_blur_a1_partition(int mode, int batch_count, float gpu_ratio, int *n_cpu, int *n_gpu);
+/* Image-level sharding over G devices: shard g owns [begin,end). */
+void mi_blur_shard_range(long long n_units, int g, int G, long long *begin, long long *end);
+
+typedef struct mi_blur_a2_geometry { /* split_image_blur.c:144-166 with HALO := halo */
+    int split_row;
+    int cpu_input_rows, cpu_output_rows;
+    int gpu_input_rows, gpu_output_rows;
+} mi_blur_a2_geometry;
+void mi_blur_a2_split(int height, float gpu_ratio, int halo, mi_blur_a2_geometry *g);
+
+typedef struct mi_blur_band {        /* K-way row split of one image over G devices */
+    int row_begin, row_end;          /* owned output rows [begin,end) */
+    int halo_top, halo_bottom;       /* halo rows needed from neighbour g-1 / g+1 (0 at image edge) */
+} mi_blur_band;
+void mi_blur_band_of(int height, int radius, int g, int G, mi_blur_band *b);
+
+/* ------------------------------------------------------------------------
+ * Approach 2 on resident row shards: halo rows move GPU<->GPU with RCCL
+ * send/recv over xGMI (the reference instead re-uploads overlapping slices
+ * from the host, split_image_blur.c:516,520,530).
+ * One communicator rank per GPU; either one process per GPU
+ * (mi_blur_comm_unique_id on rank 0, broadcast the 128 bytes by any means,
+ * mi_blur_comm_init_rank everywhere) or all ranks in one process
+ * (mi_blur_comm_init_all).
+ * ---------------------------------------------------------------------- */
+typedef struct mi_blur_comm mi_blur_comm;
+#define MI_BLUR_UNIQUE_ID_BYTES 128
+int mi_blur_comm_unique_id(uint8_t id[MI_BLUR_UNIQUE_ID_BYTES]);
+int mi_blur_comm_init_rank(mi_blur_comm **comm, int n_ranks, int rank, const uint8_t id[MI_BLUR_UNIQUE_ID_BYTES]);
+int mi_blur_comm_init_all(mi_blur_comm **comms, int n_devices, const int *devices);
+void mi_blur_comm_destroy(mi_blur_comm *comm);
+
+/* d_band: this rank's shard laid out as [halo_top rows][owned rows][halo_bottom rows]
+ * (halo_* from mi_blur_band_of; absent halos have zero rows).  Sends the first/last
+ * `radius` OWNED rows to rank-1 / rank+1 and receives their mirror into the halo
+ * rows, in one RCCL group on `stream`.  Asynchronous. */
+int mi_blur_halo_exchange(mi_blur_comm *comm, uint8_t *d_band, int width, int channels,
+                          int owned_rows, int radius, void *stream);
+
+/* Single-process form: all n ranks of a mi_blur_comm_init_all set in one RCCL group. */
+int mi_blur_halo_exchange_all(mi_blur_comm **comms, int n, uint8_t **d_bands, int width, int channels,
+                              const int *owned_rows, int radius, void **streams);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_BLUR_H */

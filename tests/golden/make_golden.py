@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* from the UNMODIFIED reference kernel (oracle/_ref).
+
+Run in the build container only (needs /root/reference and `make -C oracle ref`):
+
+    python tests/golden/make_golden.py
+
+Writes
+  blur_golden.json   known answers of gaussian_kernel.cl:19-72 under the NDRange
+                     harness (oracle/ref_harness.cpp): FNV-1a-64 of input/output and
+                     the first output bytes for LCG-filled images, small literal
+                     vectors, and Approach-2 split outputs (split_image_blur.c:511-541).
+                     The "k5" section holds 5x5 hashes from the oracle itself — the
+                     reference has no 5x5 kernel, so that section is "parity unpinned".
+  ref_images.npz     PIL-decoded pixels of the reference's sample input
+                     image_320x240.jpg and of split_output.jpg (the one saved output the
+                     reference ships, split_image_blur.c:548-553) — data, for a loose
+                     PSNR sanity check; JPEG-lossy, never bit-exact.
+Fixtures are data (inputs/expected outputs); no reference source is stored.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def hx(v: int) -> str:
+    return f"{v:016x}"
+
+
+def main() -> None:
+    O.build(ref=True)
+    gold = {"generator": "tests/golden/make_golden.py", "source": "oracle/_ref (unmodified gaussian_kernel.cl)",
+            "lcg": {"a": 1664525, "c": 1013904223, "seed": O.LCG_SEED, "byte": "s>>24"},
+            "hash": "FNV-1a-64", "k3": [], "literals": [], "a2_split": [], "k5_unpinned": []}
+
+    shapes = [(256, 256, 3), (240, 320, 3), (1080, 1920, 3), (16, 16, 3), (33, 17, 3), (3, 5, 3), (1, 1, 3),
+              (64, 64, 1), (33, 17, 1), (64, 64, 4), (31, 29, 4), (48, 64, 2), (1, 64, 3), (64, 1, 3), (2, 2, 3),
+              (8192, 8192, 3)]
+    for (h, w, c) in shapes:
+        img = O.lcg_image(h, w, c)
+        out = O.ref_blur(img)
+        assert np.array_equal(out, O.blur(img, 1)), f"oracle != reference at {h}x{w}x{c}"
+        gold["k3"].append({"h": h, "w": w, "c": c, "in_fnv": hx(O.fnv1a64(img)), "out_fnv": hx(O.fnv1a64(out)),
+                           "first": out.reshape(-1)[:8].tolist()})
+        print(f"k3 {w}x{h}x{c}: {gold['k3'][-1]['out_fnv']}", flush=True)
+
+    lits = [
+        ("impulse3x3", (3, 3, 1), [0, 0, 0, 0, 255, 0, 0, 0, 0]),
+        ("ramp3x3", (3, 3, 1), list(range(1, 10))),
+        ("rgb2x2", (2, 2, 3), [10, 20, 30, 40, 50, 60, 250, 251, 252, 253, 254, 255]),
+        ("all255_4x4", (4, 4, 3), [255] * 48),
+        ("all0_4x4", (4, 4, 3), [0] * 48),
+        ("corner_impulses_5x4", (4, 5, 1), [255, 0, 0, 0, 255, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 255, 0, 0, 0, 255]),
+        ("row1x8", (1, 8, 1), [0, 255, 0, 0, 17, 34, 51, 255]),
+        ("col8x1", (8, 1, 1), [0, 255, 0, 0, 17, 34, 51, 255]),
+    ]
+    for name, (h, w, c), vals in lits:
+        img = np.array(vals, np.uint8).reshape(h, w, c)
+        out = O.ref_blur(img)
+        gold["literals"].append({"name": name, "h": h, "w": w, "c": c, "in": vals, "out": out.reshape(-1).tolist()})
+
+    for (h, w, c, split) in [(240, 320, 3, 39), (240, 320, 3, 120), (256, 256, 3, 1), (256, 256, 3, 255), (33, 17, 3, 16)]:
+        img = O.lcg_image(h, w, c)
+        out = O.ref_split_blur(img, split)
+        whole = O.ref_blur(img)
+        gold["a2_split"].append({"h": h, "w": w, "c": c, "split_row": split, "out_fnv": hx(O.fnv1a64(out)),
+                                 "equals_whole": bool(np.array_equal(out, whole))})
+
+    for (h, w, c) in [(256, 256, 3), (1080, 1920, 3), (33, 17, 3), (3, 5, 3), (64, 64, 4), (64, 64, 1)]:
+        img = O.lcg_image(h, w, c)
+        out = O.blur(img, 2)
+        assert np.array_equal(out, O.blur_f32(img, 2)) and np.array_equal(out, O.np_blur(img, 2))
+        gold["k5_unpinned"].append({"h": h, "w": w, "c": c, "out_fnv": hx(O.fnv1a64(out)),
+                                    "first": out.reshape(-1)[:8].tolist()})
+
+    with open(os.path.join(HERE, "blur_golden.json"), "w") as f:
+        json.dump(gold, f, indent=1)
+
+    from PIL import Image
+    src = np.asarray(Image.open(os.path.join(O.REFERENCE_ROOT, "image_320x240.jpg")).convert("RGB"))
+    saved = np.asarray(Image.open(os.path.join(O.REFERENCE_ROOT, "split_output.jpg")).convert("RGB"))
+    np.savez_compressed(os.path.join(HERE, "ref_images.npz"), image_320x240=src, split_output=saved)
+    print("wrote", os.listdir(HERE))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,159 @@
+"""C-ABI surface and host logic (CPU only): the library loads, exports what include/mi_blur.h
+declares, validates arguments, refuses GPU work without a GPU, and its host-side helpers and
+CPU device agree with the oracle."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+
+def test_library_exports_every_declared_symbol(pkg, L):
+    decl = pkg.declared_symbols()
+    assert len(decl) >= 30
+    out = subprocess.run(["nm", "-D", "--defined-only", pkg.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    missing = [s for s in decl if s not in exported]
+    assert not missing, f"declared in include/mi_blur.h but not exported: {missing}"
+    assert L.mi_blur_version() == 1
+
+
+def test_c_header_compiles_as_c(pkg, tmp_path):
+    """The boundary is a C ABI: the header must compile as plain C11 and as C++."""
+    src = tmp_path / "t.c"
+    src.write_text('#include "mi_blur.h"\nint main(void){ mi_blur_timing t; (void)t; return MI_BLUR_OK; }\n')
+    inc = os.path.join(pkg.ROOT, "include")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, "-c", str(src),
+                    "-o", str(tmp_path / "t.o")], check=True)
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-x", "c++", "-I", inc, "-c", str(src),
+                    "-o", str(tmp_path / "t2.o")], check=True)
+
+
+def test_product_does_not_link_the_oracle(pkg):
+    """The product path must not route through the oracle: no dependency, no symbol."""
+    ldd = subprocess.run(["ldd", pkg.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in ldd and "ref_blur" not in ldd
+    syms = subprocess.run(["nm", "-D", pkg.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle_" not in syms and "ref_gaussian" not in syms
+    for f in os.listdir(pkg.CSRC):
+        text = open(os.path.join(pkg.CSRC, f)).read()
+        assert "oracle/" not in text.replace("with oracle/", "") or "shares no code" in text
+
+
+def test_strerror(L):
+    assert L.mi_blur_strerror(0) == b"success"
+    assert b"invalid" in L.mi_blur_strerror(-1)
+    assert b"HIP error" in L.mi_blur_strerror(-1000 - 2)
+    assert b"RCCL" in L.mi_blur_strerror(-2000 - 3)
+
+
+def test_gpu_entry_points_fail_loudly_without_gpu(pkg, L):
+    if L.mi_blur_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    a = np.zeros(64, np.uint8)
+    assert L.mi_blur_enqueue(a.ctypes.data, a.ctypes.data + 32, 2, 2, 3, 1, 1, None) == pkg.ERR_NO_DEVICE
+    h = C.c_void_p()
+    assert L.mi_blur_create(C.byref(h), 0, 8, 8, 3, 1, 1, 1, 0) == pkg.ERR_NO_DEVICE
+    assert not h
+    with pytest.raises(pkg.MiBlurError):
+        pkg.Context(0, 8, 8, 3)
+
+
+def test_argument_validation(pkg, L):
+    h = C.c_void_p()
+    cpu = pkg.DEVICE_CPU
+    assert L.mi_blur_create(None, cpu, 8, 8, 3, 1, 1, 1, 0) == pkg.ERR_INVALID
+    assert L.mi_blur_create(C.byref(h), cpu, 0, 8, 3, 1, 1, 1, 0) == pkg.ERR_INVALID
+    assert L.mi_blur_create(C.byref(h), cpu, 8, 8, 3, 3, 1, 1, 0) == pkg.ERR_INVALID      # radius 3
+    assert L.mi_blur_create(C.byref(h), cpu, 8, 8, 3, 1, 0, 1, 0) == pkg.ERR_INVALID      # max_batch 0
+    a = np.zeros(8 * 8 * 3, np.uint8)
+    b = np.zeros_like(a)
+    assert L.mi_blur_cpu_run(a.ctypes.data, a.ctypes.data, 8, 8, 3, 1, 1, 1) == pkg.ERR_INVALID   # in == out
+    assert L.mi_blur_cpu_run(a.ctypes.data, b.ctypes.data, 8, 8, 3, 0, 1, 1) == pkg.ERR_INVALID
+    assert L.mi_blur_set_option(b"no_such_knob", 1) == pkg.ERR_INVALID
+    assert L.mi_blur_set_option(b"rows_per_thread", 12) == pkg.ERR_INVALID
+    with pkg.Context(cpu, 8, 8, 3, 1, max_batch=2) as ctx:
+        assert L.mi_blur_submit(ctx.h, a.ctypes.data, b.ctypes.data, 3) == pkg.ERR_INVALID  # > max_batch
+        assert L.mi_blur_submit(ctx.h, a.ctypes.data, a.ctypes.data, 1) == pkg.ERR_INVALID
+        assert L.mi_blur_submit_band(ctx.h, a.ctypes.data, b.ctypes.data, 9, 0, 0) == pkg.ERR_INVALID
+        assert L.mi_blur_submit_band(ctx.h, a.ctypes.data, b.ctypes.data, 2, 1, 1) == pkg.ERR_INVALID
+        assert L.mi_blur_resident_alloc(ctx.h, 4) == pkg.ERR_STATE                          # CPU device has no HBM pool
+
+
+def test_a1_partition_matches_reference_formula(pkg, O):
+    for mode in (0, 1, 2):
+        for bc in (1, 30, 35, 500, 1200):
+            for ratio in (0.0, 0.1, 0.5, 0.728, 0.814, 0.837, 1.0):
+                assert pkg.a1_partition(mode, bc, ratio) == O.a1_partition(mode, bc, ratio)
+    assert pkg.a1_partition(0, 35, 0.728) == (10, 25)          # data/approach1/35_run_1.txt distribution
+
+
+def test_a2_geometry_matches_reference_formula(pkg, O):
+    for h in (3, 16, 240, 256, 1080, 8192):
+        for halo in (1, 2):
+            for ratio in (0.0, 0.01, 0.163, 0.5, 0.837, 0.99, 1.0):
+                assert pkg.a2_split(h, ratio, halo) == O.a2_geometry(h, ratio, halo)
+    assert pkg.a2_split(240, 0.837, 1)["split_row"] == 39      # data/approach2/35_run_1.txt:16
+
+
+def test_shard_range_and_bands_tile_exactly(pkg):
+    for n in (1, 7, 5000, 50000):
+        for G in (1, 2, 3, 8):
+            r = [pkg.shard_range(n, g, G) for g in range(G)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[i][1] == r[i + 1][0] for i in range(G - 1))
+            assert max(e - b for b, e in r) - min(e - b for b, e in r) <= 1
+    for H in (16, 240, 1080, 8192):
+        for R in (1, 2):
+            for G in (1, 2, 5, 8):
+                bands = [pkg.band_of(H, R, g, G) for g in range(G)]
+                assert bands[0]["row_begin"] == 0 and bands[-1]["row_end"] == H
+                assert bands[0]["halo_top"] == 0 and bands[-1]["halo_bottom"] == 0
+                for i in range(G - 1):
+                    assert bands[i]["row_end"] == bands[i + 1]["row_begin"]
+                    assert bands[i]["halo_bottom"] == R and bands[i + 1]["halo_top"] == R
+
+
+@pytest.mark.parametrize("h,w,c", [(1, 1, 3), (3, 5, 3), (33, 17, 1), (17, 16, 4), (9, 2, 2), (240, 320, 3), (5, 7, 5)])
+@pytest.mark.parametrize("radius", [1, 2])
+def test_cpu_device_matches_oracle(pkg, L, O, h, w, c, radius):
+    """The `cpu` mode device (separable, vectorised) is a different algorithm from the oracle
+    (per-pixel 2-D sum): they must agree byte for byte."""
+    n = 3
+    rng = np.random.default_rng(h + w + c)
+    for img in (O.lcg_stream(n, h, w, c), rng.integers(0, 256, (n, h, w, c), dtype=np.uint8)):
+        for nt in (1, 4):
+            out = np.zeros_like(img)
+            pkg.check(L.mi_blur_cpu_run(img.ctypes.data, out.ctypes.data, w, h, c, radius, n, nt))
+            want = np.stack([O.blur(np.ascontiguousarray(img[i]), radius) for i in range(n)])
+            assert np.array_equal(out, want)
+
+
+def test_cpu_context_submit_and_band(pkg, L, O):
+    h, w, c = 48, 40, 3
+    img = O.lcg_stream(6, h, w, c)
+    with pkg.Context(pkg.DEVICE_CPU, w, h, c, 1, max_batch=6, n_threads=2) as ctx:
+        out = np.zeros_like(img)
+        ctx.submit(img.ctypes.data, out.ctypes.data, 4)
+        ctx.submit(img[4:].ctypes.data, out[4:].ctypes.data, 2)
+        tm = ctx.sync()
+        assert np.array_equal(out, O.blur_batch(img, 1))
+        assert tm["images"] == 6 and tm["launches"] == 2 and tm["bytes_alg"] == 2 * img.size
+        assert tm["kernel_ms"] > 0 and tm["h2d_ms"] == 0
+        # Approach 2 on the CPU device: top band [0, split+1) and bottom band [split-1, H)
+        one = np.ascontiguousarray(img[0])
+        whole = O.blur(one, 1)
+        split = 17
+        top, bot = np.zeros((split, w, c), np.uint8), np.zeros((h - split, w, c), np.uint8)
+        ctx.submit_band(one.ctypes.data, top.ctypes.data, split + 1, 0, 1)
+        ctx.submit_band(one[split - 1:].ctypes.data, bot.ctypes.data, h - split + 1, 1, 0)
+        ctx.sync()
+        assert np.array_equal(np.concatenate([top, bot]), whole)
+
+
+def test_synthetic_stream_matches_oracle_generator(pkg, L, O):
+    a = np.empty((5, 8, 12, 3), np.uint8)
+    L.mi_blur_fill_synthetic(a.ctypes.data, 12, 8, 3, 40, 5, 3)
+    assert np.array_equal(a, O.lcg_stream(5, 8, 12, 3, first_index=40))
+    assert L.mi_blur_fnv1a64(a.ctypes.data, a.size) == O.fnv1a64(a)

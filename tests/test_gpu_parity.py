@@ -1,0 +1,267 @@
+"""Parity of the HIP path against the oracle, through the C ABI, on a real MI355X (-m gpu).
+
+Bit-exact is the bar (uint8 path).  torch is used for device memory only; every blur goes
+through libmi_blur.so, and the tests fail if the library cannot run on the GPU (no fallback).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda(L):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    assert L.mi_blur_device_count() >= 1, "libmi_blur.so sees no HIP device"
+    torch.cuda.set_device(0)
+    return torch
+
+
+def gpu_blur(pkg, L, torch, host, radius, variant=0, y0=None, y1=None, opts=None):
+    """host: N x H x W x C uint8 -> output rows [y0,y1) of every band, via mi_blur_enqueue_ex."""
+    n, h, w, c = host.shape
+    y0 = 0 if y0 is None else y0
+    y1 = h if y1 is None else y1
+    for k, v in (opts or {}).items():
+        pkg.check(L.mi_blur_set_option(k.encode(), v), f"set_option {k}")
+    d_in = torch.from_numpy(host).cuda()
+    d_out = torch.full((n, y1 - y0, w, c), 0xA5, dtype=torch.uint8, device="cuda")
+    guard = torch.full((4096,), 0x5A, dtype=torch.uint8, device="cuda")   # allocated right after: catches overruns loosely
+    rc = L.mi_blur_enqueue_ex(d_in.data_ptr(), d_out.data_ptr(), w, h, c, radius, n, y0, y1, variant,
+                              torch.cuda.current_stream().cuda_stream)
+    pkg.check(rc, "mi_blur_enqueue_ex")
+    torch.cuda.synchronize()
+    assert bool((guard == 0x5A).all())
+    assert bool((d_in.cpu() == torch.from_numpy(host)).all()), "input buffer modified"
+    return d_out.cpu().numpy()
+
+
+def reset_opts(L):
+    L.mi_blur_set_option(b"stage_dma", 1)
+    L.mi_blur_set_option(b"rows_per_thread", 8)
+    L.mi_blur_set_option(b"xcd_remap", 1)
+
+
+def want_batch(O, host, radius):
+    return np.stack([O.blur(np.ascontiguousarray(host[i]), radius) for i in range(host.shape[0])])
+
+
+# shapes: (H, W, C).  pitch % 16 == 0 -> tiled kernel eligible; the rest exercise the generic kernel.
+TILED_SHAPES = [(16, 16, 3), (1, 16, 1), (2, 16, 3), (3, 32, 2), (5, 64, 4), (9, 48, 3), (33, 80, 3), (64, 80, 3),
+                (240, 320, 3), (256, 256, 3), (47, 1360, 3), (40, 4096, 1), (31, 1040, 4), (100, 16, 4),
+                (131, 112, 1), (17, 2064, 2)]
+GENERIC_SHAPES = [(1, 1, 3), (3, 5, 3), (33, 17, 3), (33, 17, 1), (31, 29, 4), (2, 2, 3), (64, 1, 3), (1, 64, 3),
+                  (7, 9, 5), (50, 37, 2)]
+
+
+def adversarial(O, h, w, c, n, seed):
+    rng = np.random.default_rng(seed)
+    imgs = [O.lcg_stream(n, h, w, c), rng.integers(0, 256, (n, h, w, c), dtype=np.uint8),
+            np.full((n, h, w, c), 255, np.uint8)]
+    imp = np.zeros((n, h, w, c), np.uint8)           # impulses at corners / edges
+    imp[:, 0, 0, :] = 255; imp[:, -1, -1, :] = 255; imp[:, 0, -1, 0] = 255; imp[:, -1, 0, -1] = 255
+    imp[:, h // 2, 0, :] = 255; imp[:, h // 2, -1, :] = 255; imp[:, 0, w // 2, :] = 255; imp[:, -1, w // 2, :] = 255
+    imgs.append(imp)
+    return imgs
+
+
+@pytest.mark.parametrize("h,w,c", TILED_SHAPES)
+@pytest.mark.parametrize("radius", [1, 2])
+def test_tiled_kernel_bit_exact(pkg, L, O, torch_cuda, h, w, c, radius):
+    n = 3
+    try:
+        for host in adversarial(O, h, w, c, n, h * 7 + w):
+            want = want_batch(O, host, radius)
+            for opts in ({"stage_dma": 1, "rows_per_thread": 8, "xcd_remap": 1},
+                         {"stage_dma": 0, "rows_per_thread": 16, "xcd_remap": 0}):
+                got = gpu_blur(pkg, L, torch_cuda, host, radius, pkg.VARIANT_TILED, opts=opts)
+                assert np.array_equal(got, want), f"{(got != want).sum()} bytes differ, opts={opts}"
+    finally:
+        reset_opts(L)
+
+
+@pytest.mark.parametrize("opts", [{"stage_dma": 1, "rows_per_thread": 16}, {"stage_dma": 0, "rows_per_thread": 8}])
+@pytest.mark.parametrize("radius", [1, 2])
+def test_tiled_kernel_option_cross(pkg, L, O, torch_cuda, opts, radius):
+    try:
+        for (h, w, c) in [(256, 256, 3), (75, 1360, 3), (40, 64, 4)]:
+            host = O.lcg_stream(2, h, w, c)
+            got = gpu_blur(pkg, L, torch_cuda, host, radius, pkg.VARIANT_TILED, opts=opts)
+            assert np.array_equal(got, want_batch(O, host, radius))
+    finally:
+        reset_opts(L)
+
+
+@pytest.mark.parametrize("h,w,c", GENERIC_SHAPES + TILED_SHAPES[:8])
+@pytest.mark.parametrize("radius", [1, 2])
+def test_generic_kernel_bit_exact(pkg, L, O, torch_cuda, h, w, c, radius):
+    for host in adversarial(O, h, w, c, 2, h * 3 + w):
+        got = gpu_blur(pkg, L, torch_cuda, host, radius, pkg.VARIANT_GENERIC)
+        assert np.array_equal(got, want_batch(O, host, radius))
+
+
+def test_auto_dispatch_and_ineligible_tiled(pkg, L, O, torch_cuda):
+    host = O.lcg_stream(2, 33, 17, 3)                 # pitch 51: not a multiple of 16
+    assert np.array_equal(gpu_blur(pkg, L, torch_cuda, host, 1, pkg.VARIANT_AUTO), want_batch(O, host, 1))
+    d = torch_cuda.zeros(2 * 33 * 17 * 3, dtype=torch_cuda.uint8, device="cuda")
+    o = torch_cuda.zeros_like(d)
+    assert L.mi_blur_enqueue_ex(d.data_ptr(), o.data_ptr(), 17, 33, 3, 1, 2, 0, 33, pkg.VARIANT_TILED, None) == pkg.ERR_INVALID
+    assert L.mi_blur_enqueue_ex(d.data_ptr(), d.data_ptr(), 17, 33, 3, 1, 2, 0, 33, 0, None) == pkg.ERR_INVALID
+    assert L.mi_blur_enqueue_ex(d.data_ptr(), o.data_ptr(), 17, 33, 3, 3, 2, 0, 33, 0, None) == pkg.ERR_INVALID
+    assert L.mi_blur_enqueue_ex(d.data_ptr(), o.data_ptr(), 17, 33, 3, 1, 2, 5, 5, 0, None) == pkg.ERR_INVALID
+    assert L.mi_blur_enqueue_ex(d.data_ptr(), o.data_ptr(), 17, 33, 3, 1, 0, 0, 33, 0, None) == pkg.OK     # empty batch
+    # misaligned device pointers fall back to the generic kernel under AUTO
+    host = O.lcg_stream(1, 16, 16, 3)
+    buf = torch_cuda.zeros(host.size + 64, dtype=torch_cuda.uint8, device="cuda")
+    out = torch_cuda.zeros(host.size + 64, dtype=torch_cuda.uint8, device="cuda")
+    buf[3:3 + host.size] = torch_cuda.from_numpy(host.reshape(-1)).cuda()
+    pkg.check(L.mi_blur_enqueue(buf.data_ptr() + 3, out.data_ptr() + 5, 16, 16, 3, 1, 1, None))
+    torch_cuda.cuda.synchronize()
+    assert np.array_equal(out[5:5 + host.size].cpu().numpy().reshape(host.shape), want_batch(O, host, 1))
+
+
+def test_golden_hashes_on_gpu(pkg, L, O, torch_cuda, golden):
+    """The committed reference-kernel known answers, reproduced by the HIP path."""
+    for e in golden["k3"]:
+        if e["h"] * e["w"] * e["c"] > 64 << 20:
+            continue
+        host = O.lcg_image(e["h"], e["w"], e["c"])[None]
+        got = gpu_blur(pkg, L, torch_cuda, host, 1)
+        assert f"{O.fnv1a64(got):016x}" == e["out_fnv"], e
+    for lit in golden["literals"]:
+        host = np.array(lit["in"], np.uint8).reshape(1, lit["h"], lit["w"], lit["c"])
+        assert gpu_blur(pkg, L, torch_cuda, host, 1).reshape(-1).tolist() == lit["out"], lit["name"]
+    for e in golden["k5_unpinned"]:
+        host = O.lcg_image(e["h"], e["w"], e["c"])[None]
+        assert f"{O.fnv1a64(gpu_blur(pkg, L, torch_cuda, host, 2)):016x}" == e["out_fnv"]
+
+
+def test_band_semantics_and_split_equals_whole(pkg, L, O, torch_cuda):
+    """Approach 2 (split_image_blur.c:401,414,511-541): band kernels with the band height as
+    `height`, halo rows dropped; every split row and K-way split reproduce the whole image."""
+    for (h, w, c) in [(240, 320, 3), (64, 48, 4), (37, 17, 3)]:
+        img = O.lcg_image(h, w, c)
+        for radius in (1, 2):
+            whole = O.blur(img, radius)
+            for split in sorted({radius, 39 % h, h // 2, h - radius}):
+                if split < radius or split > h - radius:
+                    continue
+                top_in = np.ascontiguousarray(img[:split + radius])[None]
+                bot_in = np.ascontiguousarray(img[split - radius:])[None]
+                top = gpu_blur(pkg, L, torch_cuda, top_in, radius, y0=0, y1=split)
+                bot = gpu_blur(pkg, L, torch_cuda, bot_in, radius, y0=radius, y1=h - split + radius)
+                assert np.array_equal(np.concatenate([top[0], bot[0]]), whole), (h, w, c, radius, split)
+            for G in (2, 3, 8):
+                parts = []
+                for g in range(G):
+                    b = pkg.band_of(h, radius, g, G)
+                    band = np.ascontiguousarray(img[b["row_begin"] - b["halo_top"]: b["row_end"] + b["halo_bottom"]])[None]
+                    parts.append(gpu_blur(pkg, L, torch_cuda, band, radius, y0=b["halo_top"],
+                                          y1=b["halo_top"] + b["row_end"] - b["row_begin"])[0])
+                assert np.array_equal(np.concatenate(parts), whole)
+
+
+def test_context_submit_pageable_and_pinned(pkg, L, O, torch_cuda):
+    h, w, c, n = 240, 320, 3, 35
+    host = O.lcg_stream(n, h, w, c)
+    want = O.blur_batch(host, 1)
+    with pkg.Context(0, w, h, c, 1, max_batch=n, n_slots=2) as ctx:
+        out = np.zeros_like(host)
+        ctx.submit(host.ctypes.data, out.ctypes.data, n)                     # pageable caller memory
+        ctx.submit(host[:10].ctypes.data, out[:10].ctypes.data, 10)          # second slot, overlapping range rewritten
+        tm = ctx.sync()
+        assert np.array_equal(out, want)
+        assert tm["images"] == n + 10 and tm["launches"] == 2
+        assert tm["kernel_ms"] > 0 and tm["h2d_ms"] > 0 and tm["d2h_ms"] > 0
+        assert tm["bytes_h2d"] == (n + 10) * h * w * c
+        # pinned caller memory: DMA straight from/to it
+        nbytes = host.nbytes
+        p_in, p_out = L.mi_blur_host_alloc(nbytes), L.mi_blur_host_alloc(nbytes)
+        assert p_in and p_out
+        C.memmove(p_in, host.ctypes.data, nbytes)
+        ctx.submit(p_in, p_out, n)
+        ctx.sync()
+        got = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(p_out)).reshape(host.shape).copy()
+        L.mi_blur_host_free(p_in); L.mi_blur_host_free(p_out)
+        assert np.array_equal(got, want)
+        # Approach-2 bands through the context
+        one = np.ascontiguousarray(host[0]); split = 39
+        top, bot = np.zeros((split, w, c), np.uint8), np.zeros((h - split, w, c), np.uint8)
+        ctx.submit_band(one.ctypes.data, top.ctypes.data, split + 1, 0, 1)
+        ctx.submit_band(one[split - 1:].ctypes.data, bot.ctypes.data, h - split + 1, 1, 0)
+        ctx.sync()
+        assert np.array_equal(np.concatenate([top, bot]), want[0])
+
+
+def test_resident_stream(pkg, L, O, torch_cuda):
+    """Device-resident image stream: pool fill (synthetic LCG), batched passes, wrap-around."""
+    h, w, c, pool = 64, 64, 3, 100
+    with pkg.Context(0, w, h, c, 1, max_batch=35, n_slots=3) as ctx:
+        ctx.resident_alloc(pool)
+        ctx.resident_fill_synthetic(0)
+        ctx.resident_run(250, 35, timed=True)         # 8 launches (7x35 + 5), wraps the 100-image pool
+        tm = ctx.sync()
+        assert tm["images"] == 250 and tm["launches"] == 8 and tm["kernel_ms"] > 0
+        assert tm["bytes_alg"] == 250 * 2 * h * w * c
+        out = np.zeros((pool, h, w, c), np.uint8)
+        ctx.resident_download(0, out.ctypes.data, pool)
+        src = O.lcg_stream(pool, h, w, c)
+        # pool images 0..69 are certainly written (35+35 twice over), and every written image must be exact
+        want = O.blur_batch(src, 1)
+        assert np.array_equal(out[:70], want[:70])
+        ctx.reset_timing()
+        ctx.resident_run(pool, pool, timed=False)     # one launch over the whole pool
+        tm = ctx.sync()
+        assert tm["launches"] == 1 and tm["kernel_ms"] == 0
+        ctx.resident_download(0, out.ctypes.data, pool)
+        assert np.array_equal(out, want)
+
+
+def test_full_size_properties(pkg, L, O, torch_cuda):
+    """BASELINE sizes, checked through size-independent properties (the oracle would take minutes):
+    (i) 5000x256x256x3 stream: every output image of the synthetic stream hashes like the oracle's on a
+    sample, and blur(all-255)=255 / blur(0)=0; (ii) 1920x1080 5x5 and 8192x8192 3x3: K-way split ==
+    whole image (computed on the GPU both ways), plus oracle rows on a sampled band."""
+    torch = torch_cuda
+    h, w, c, n = 256, 256, 3, 5000
+    with pkg.Context(0, w, h, c, 1, max_batch=35, n_slots=2) as ctx:
+        ctx.resident_alloc(n)
+        ctx.resident_fill_synthetic(0)
+        ctx.resident_run(n, 35)
+        ctx.sync()
+        for idx in (0, 1, 34, 35, 2499, 4969, 4999):
+            got = np.zeros((1, h, w, c), np.uint8)
+            ctx.resident_download(idx, got.ctypes.data, 1)
+            assert np.array_equal(got[0], O.blur(O.lcg_stream(1, h, w, c, first_index=idx)[0], 1)), idx
+    # 8192x8192x3: whole vs 8-way split on the GPU; sampled rows vs oracle
+    H = W = 8192
+    img = O.lcg_image(H, W, 3)
+    d_in = torch.from_numpy(img).cuda()
+    d_whole = torch.empty_like(d_in)
+    pkg.check(L.mi_blur_enqueue(d_in.data_ptr(), d_whole.data_ptr(), W, H, 3, 1, 1, None))
+    d_split = torch.empty_like(d_in)
+    pitch = W * 3
+    for g in range(8):
+        b = pkg.band_of(H, 1, g, 8)
+        r0 = b["row_begin"] - b["halo_top"]
+        rows = b["row_end"] + b["halo_bottom"] - r0
+        pkg.check(L.mi_blur_enqueue_band(d_in.data_ptr() + r0 * pitch, d_split.data_ptr() + b["row_begin"] * pitch,
+                                         W, rows, 3, 1, b["halo_top"], b["halo_top"] + b["row_end"] - b["row_begin"], None))
+    torch.cuda.synchronize()
+    assert bool((d_whole == d_split).all())
+    whole = d_whole.cpu().numpy()
+    for r0 in (0, 1023, 4090, 8192 - 40):
+        band = np.ascontiguousarray(img[max(r0 - 1, 0): r0 + 41])
+        ref = O.blur(band, 1)
+        off = r0 - max(r0 - 1, 0)
+        assert np.array_equal(whole[r0:r0 + 39], ref[off:off + 39]), r0
+    # 1920x1080 5x5
+    img = O.lcg_image(1080, 1920, 3)
+    got = gpu_blur(pkg, L, torch, img[None], 2)[0]
+    assert np.array_equal(got[:64], O.blur(np.ascontiguousarray(img[:66]), 2)[:64])
+    assert np.array_equal(got[-64:], O.blur(np.ascontiguousarray(img[-66:]), 2)[-64:])
+    flat = gpu_blur(pkg, L, torch, np.full((1, 1080, 1920, 3), 255, np.uint8), 2)
+    assert int(flat.min()) == 255
