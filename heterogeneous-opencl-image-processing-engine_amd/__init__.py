@@ -102,6 +102,15 @@ def lib() -> C.CDLL:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise FileNotFoundError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    # torch wheels bundle their own libamdhip64/libhsa-runtime64 and load them by path.  If this
+    # library were loaded first it would pull /opt/rocm's copies in and the process would hold
+    # TWO HIP runtimes fighting over the device (measured: device count 0 / torch unavailable).
+    # Harness processes use torch for device memory, so load torch first: libmi_blur.so then binds
+    # to the already-loaded runtime by soname.  (The C++ hosts never load torch: one runtime.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i, u8p = C.c_void_p, C.c_int, C.c_void_p
     sig = {
@@ -127,6 +136,7 @@ def lib() -> C.CDLL:
         "mi_blur_resident_in": (vp, [vp]),
         "mi_blur_resident_out": (vp, [vp]),
         "mi_blur_resident_run": (i, [vp, i, i, i]),
+        "mi_blur_timed_coverage": (None, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "mi_blur_cpu_run": (i, [u8p, u8p, i, i, i, i, i, i]),
         "mi_blur_fill_synthetic": (None, [u8p, i, i, i, i, i, i]),
         "mi_blur_fnv1a64": (C.c_uint64, [u8p, C.c_size_t]),
@@ -233,5 +243,11 @@ class Context:
     def resident_download(self, pool_index: int, host_out, n_images: int) -> None:
         check(lib().mi_blur_resident_download(self.h, pool_index, host_out, n_images), "mi_blur_resident_download")
 
-    def resident_run(self, n_images: int, batch: int, timed: bool = False) -> None:
+    def resident_run(self, n_images: int, batch: int, timed: int | bool = 0) -> None:
+        """timed: 0/False none, 1/True every launch, n every n-th launch carries timestamp events."""
         check(lib().mi_blur_resident_run(self.h, n_images, batch, int(timed)), "mi_blur_resident_run")
+
+    def timed_coverage(self) -> tuple[int, int]:
+        n, b = C.c_uint64(), C.c_uint64()
+        lib().mi_blur_timed_coverage(self.h, C.byref(n), C.byref(b))
+        return n.value, b.value

@@ -16,18 +16,26 @@
 //   * one workgroup stages a (TH + 2R) x (ncols + 2) tile of 16-byte chunks in LDS —
 //     the output tile plus an R-row halo above/below (rows clamped at the band edge at
 //     staging time, so the y-clamp costs nothing later) and one 16-byte halo chunk left
-//     and right — with 16 B/lane coalesced loads, either LDS-DMA (global_load_lds_dwordx4,
-//     no VGPR round trip) or registers;
-//   * each thread owns one 16-byte chunk column and RPG consecutive rows: per row it
-//     reads 8+16+8 bytes from LDS, forms the horizontal sums of its 16 output bytes in
-//     packed u16 (v_alignbyte_b32 for the +-C / +-2C byte shifts, v_perm_b32 to widen,
-//     v_pk_* arithmetic), keeps a 2R+1-row sliding window of those sums in registers,
-//     combines vertically, narrows with one v_perm_b32 per dword and stores 16 bytes;
-//   * the x-clamp is synthesised in registers only by the lanes whose chunk touches the
-//     row start/end (byte at position -k equals byte (-k mod C); mirror at the end).
+//     and right.  Staging is one tile row (or several short ones) per wave-instruction:
+//     16 B/lane coalesced global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip; the LDS
+//     image of a row is exactly the lanes in order), a register path is kept for A/B;
+//   * each thread owns one 16-byte chunk column and RPG consecutive rows.  Per row it reads
+//     8+16+8 bytes from LDS and splits every dword into its EVEN bytes (x & 0x00ff00ff) and
+//     ODD bytes (v_perm) — two 16-bit fields per dword.  No field ever exceeds 16 bits
+//     (max 65280), so field arithmetic is plain 32-bit SWAR: v_add_u32 / v_lshl_add_u32
+//     (VOP2/VOP3 scalar-width ops, measured ~1.5-2.6 cycles per wave-instruction against
+//     2.6 for every v_pk_* / v_perm; tools/ubench/valu_rate.hip).  A byte shift of +-C
+//     maps even/odd fields onto whole dwords of the other (or same) parity array, or onto a
+//     16-bit funnel shift (v_alignbit_b32) — for C=3 half of the taps are free;
+//   * a 2R+1-row sliding window of horizontal sums lives in registers; the vertical
+//     combine, the final >>4 (>>8) and the even/odd re-interleave are 3 ops per output dword;
+//   * the x-clamp is synthesised in registers (v_perm + v_cndmask) only in waves that contain
+//     a lane whose chunk touches the row start/end (byte at position -k equals byte
+//     (-k mod C); mirror at the end).
 //   HBM traffic = each input byte once + each output byte once, plus the tile-edge halo
 //   (2R/TH of the rows, 2/ncols of the columns), which neighbouring tiles keep in L2
-//   (blockIdx -> tile map gives each XCD a contiguous run of tiles).
+//   (blockIdx -> tile map gives each XCD a contiguous run of tiles).  Measured with
+//   rocprofv3 PMC: FETCH_SIZE*2 + WRITE_SIZE within 0.1-2.5 % of the algorithmic bytes.
 //
 // Generic kernel: one output byte per thread, any shape (pitch not a multiple of 16,
 // unaligned pointers).  Correct everywhere, fast nowhere.
@@ -45,17 +53,15 @@ namespace mi_blur {
 // device helpers
 // ----------------------------------------------------------------------------------
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-
 __device__ __forceinline__ u16x2 as_pk(uint32_t x) { return __builtin_bit_cast(u16x2, x); }
 __device__ __forceinline__ uint32_t as_u32(u16x2 x) { return __builtin_bit_cast(uint32_t, x); }
-// bytes (b0,b1,b2,b3) -> (b0 | b1<<16) and (b2 | b3<<16); selector 0x0c = constant 0x00
-__device__ __forceinline__ u16x2 widen_lo(uint32_t x) { return as_pk(__builtin_amdgcn_perm(0u, x, 0x0c010c00u)); }
-__device__ __forceinline__ u16x2 widen_hi(uint32_t x) { return as_pk(__builtin_amdgcn_perm(0u, x, 0x0c030c02u)); }
-// high bytes of four u16 (lo pair, hi pair) -> one dword of 4 output bytes
-__device__ __forceinline__ uint32_t narrow_hi8(u16x2 lo, u16x2 hi)
-{
-    return __builtin_amdgcn_perm(as_u32(hi), as_u32(lo), 0x07050301u);
-}
+
+constexpr uint32_t EVEN_MASK = 0x00ff00ffu;
+// even bytes (b0 | b2<<16) and odd bytes (b1 | b3<<16) of a dword as two 16-bit fields
+__device__ __forceinline__ uint32_t even_of(uint32_t x) { return x & EVEN_MASK; }
+__device__ __forceinline__ uint32_t odd_of(uint32_t x) { return __builtin_amdgcn_perm(0u, x, 0x0c030c01u); }
+// 6*c + t on both 16-bit fields (v_pk_mad_u16; a 32-bit multiply would be quarter rate)
+__device__ __forceinline__ uint32_t mad6(uint32_t c, uint32_t t) { return as_u32(as_pk(c) * (unsigned short)6 + as_pk(t)); }
 
 // x-clamp selectors.  Left: the dword holding row-stream bytes [-4q, -4q+3] (q = 1, 2)
 // when the chunk starts the row: byte at position p < 0 is a copy of byte (p mod C)
@@ -84,58 +90,63 @@ constexpr uint32_t sel_right(int C, int q)
     return s;
 }
 
-// w[0..7] = row-stream bytes [-8, 24) around this thread's chunk (chunk = w[2..5]).
-// Returns the dword of bytes [4*I + K, 4*I + K + 4).
-template <int K, int I>
-__device__ __forceinline__ uint32_t shifted(const uint32_t (&w)[8])
+// Ew[j] / Ow[j] = even / odd bytes of window dword j, the window being row-stream bytes
+// [-8, 24) around this thread's chunk (chunk = dwords 2..5).  tap<K, PI, I> = the two
+// 16-bit fields that sit K bytes away from the PI-parity (0 even, 1 odd) bytes of chunk
+// dword I: bytes 4I+PI+K and 4I+PI+K+2.  They are consecutive elements of one parity
+// array, i.e. either a whole dword of it or a 16-bit funnel shift of two.
+template <int K, int PI, int I>
+__device__ __forceinline__ uint32_t tap(const uint32_t (&Ew)[8], const uint32_t (&Ow)[8])
 {
-    constexpr int pos = 8 + 4 * I + K;
-    static_assert(pos >= 0 && pos <= 28, "shift out of the staged window");
-    constexpr int q = pos >> 2, s = pos & 3;
-    if constexpr (s == 0) return w[q];
-    else return __builtin_amdgcn_alignbyte(w[q + 1], w[q], s);
-}
-
-// Horizontal tap sums of one chunk dword I: two packed-u16 pairs.
-template <int C, int R, int I>
-__device__ __forceinline__ void hsum_dword(const uint32_t (&w)[8], u16x2 &lo, u16x2 &hi)
-{
-    const uint32_t c = w[2 + I];
-    if constexpr (R == 1) {
-        const uint32_t l = shifted<-C, I>(w), r = shifted<C, I>(w);
-        lo = widen_lo(l) + widen_lo(r) + widen_lo(c) * (unsigned short)2;
-        hi = widen_hi(l) + widen_hi(r) + widen_hi(c) * (unsigned short)2;
+    constexpr int q0 = 8 + 4 * I + PI + K;      // window byte index of the first field
+    static_assert(q0 >= 0 && q0 + 2 < 32, "tap outside the staged window");
+    constexpr int e0 = q0 >> 1, j = e0 >> 1;    // element / dword index in the parity array
+    if constexpr ((q0 & 1) == 0) {
+        if constexpr ((e0 & 1) == 0) return Ew[j];
+        else return __builtin_amdgcn_alignbit(Ew[j + 1], Ew[j], 16);
     } else {
-        const uint32_t l2 = shifted<-2 * C, I>(w), l1 = shifted<-C, I>(w);
-        const uint32_t r1 = shifted<C, I>(w), r2 = shifted<2 * C, I>(w);
-        lo = (widen_lo(l2) + widen_lo(r2)) + (widen_lo(l1) + widen_lo(r1)) * (unsigned short)4 +
-             widen_lo(c) * (unsigned short)6;
-        hi = (widen_hi(l2) + widen_hi(r2)) + (widen_hi(l1) + widen_hi(r1)) * (unsigned short)4 +
-             widen_hi(c) * (unsigned short)6;
+        if constexpr ((e0 & 1) == 0) return Ow[j];
+        else return __builtin_amdgcn_alignbit(Ow[j + 1], Ow[j], 16);
     }
 }
 
-// Horizontal pass of one staged LDS row for this thread's chunk: h[0..7] = 16 sums.
+// Horizontal tap sum for the PI-parity bytes of chunk dword I (two 16-bit fields).
+template <int C, int R, int PI, int I>
+__device__ __forceinline__ uint32_t hsum(const uint32_t (&Ew)[8], const uint32_t (&Ow)[8])
+{
+    const uint32_t c = PI ? Ow[2 + I] : Ew[2 + I];
+    if constexpr (R == 1) {
+        return (tap<-C, PI, I>(Ew, Ow) + tap<C, PI, I>(Ew, Ow)) + (c << 1);          // <= 1020
+    } else {
+        const uint32_t t = tap<-2 * C, PI, I>(Ew, Ow) + tap<2 * C, PI, I>(Ew, Ow);
+        const uint32_t u = tap<-C, PI, I>(Ew, Ow) + tap<C, PI, I>(Ew, Ow);
+        return mad6(c, (u << 2) + t);                                                 // <= 4080
+    }
+}
+
+// Horizontal pass of one staged LDS row for this thread's chunk:
+// h[0..3] = even-byte sums of chunk dwords 0..3, h[4..7] = odd-byte sums.
 template <int C, int R>
-__device__ __forceinline__ void hrow(const uint8_t *lp, bool at_start, bool at_end, u16x2 (&h)[8])
+__device__ __forceinline__ void hrow(const uint8_t *lp, bool any_edge, bool at_start, bool at_end, uint32_t (&h)[8])
 {
     uint32_t w[8];
     const uint2 a = *reinterpret_cast<const uint2 *>(lp - 8);
     const uint4 c = *reinterpret_cast<const uint4 *>(lp);
     const uint2 b = *reinterpret_cast<const uint2 *>(lp + 16);
     w[0] = a.x; w[1] = a.y; w[2] = c.x; w[3] = c.y; w[4] = c.z; w[5] = c.w; w[6] = b.x; w[7] = b.y;
-    if (at_start) {
-        w[1] = __builtin_amdgcn_perm(0u, w[2], sel_left(C, 1));
-        w[0] = __builtin_amdgcn_perm(0u, w[2], sel_left(C, 2));
+    if (any_edge) {   // wave-uniform: some lane's chunk starts or ends the image row
+        w[1] = at_start ? __builtin_amdgcn_perm(0u, w[2], sel_left(C, 1)) : w[1];
+        w[0] = at_start ? __builtin_amdgcn_perm(0u, w[2], sel_left(C, 2)) : w[0];
+        w[6] = at_end ? __builtin_amdgcn_perm(0u, w[5], sel_right(C, 0)) : w[6];
+        w[7] = at_end ? __builtin_amdgcn_perm(0u, w[5], sel_right(C, 1)) : w[7];
     }
-    if (at_end) {
-        w[6] = __builtin_amdgcn_perm(0u, w[5], sel_right(C, 0));
-        w[7] = __builtin_amdgcn_perm(0u, w[5], sel_right(C, 1));
-    }
-    hsum_dword<C, R, 0>(w, h[0], h[1]);
-    hsum_dword<C, R, 1>(w, h[2], h[3]);
-    hsum_dword<C, R, 2>(w, h[4], h[5]);
-    hsum_dword<C, R, 3>(w, h[6], h[7]);
+    uint32_t Ew[8], Ow[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { Ew[j] = even_of(w[j]); Ow[j] = odd_of(w[j]); }   // unused ones are dead code
+    h[0] = hsum<C, R, 0, 0>(Ew, Ow); h[1] = hsum<C, R, 0, 1>(Ew, Ow);
+    h[2] = hsum<C, R, 0, 2>(Ew, Ow); h[3] = hsum<C, R, 0, 3>(Ew, Ow);
+    h[4] = hsum<C, R, 1, 0>(Ew, Ow); h[5] = hsum<C, R, 1, 1>(Ew, Ow);
+    h[6] = hsum<C, R, 1, 2>(Ew, Ow); h[7] = hsum<C, R, 1, 3>(Ew, Ow);
 }
 
 struct TiledParams {
@@ -144,7 +155,7 @@ struct TiledParams {
     long long in_stride, out_stride;  // bytes per image
     int pitch, cpr;                   // bytes per row, 16-byte chunks per row
     int H, y0, y1;                    // band rows (clamp range), output rows [y0,y1)
-    int ncols, nstrips;               // chunk columns per strip, strips per row
+    int ncols, nstrips;               // chunk columns per strip (<= 62), strips per row
     int TH, ntiles_y, ngroups;        // output rows per tile, row tiles per image, row groups per tile
     unsigned nblocks;
     int xcd;
@@ -175,29 +186,34 @@ __global__ __launch_bounds__(256) void blur_tiled_kernel(const TiledParams p)
     const int rows_out = min(p.TH, p.y1 - ty0);
     const int x0c = strip * p.ncols;                  // first chunk column of the strip
     const int nc = min(p.ncols, p.cpr - x0c);
-    const int cpr2 = nc + 2;                          // + one halo chunk each side
-    const int nchunks = (rows_out + 2 * R) * cpr2;
+    const int cpr2 = nc + 2;                          // + one halo chunk each side (<= 64)
+    const int nrows = rows_out + 2 * R;
     const uint8_t *img_in = p.in + (long long)img * p.in_stride;
 
-    // ---- stage: LDS chunk i <-> (row i / cpr2, column i % cpr2); rows clamp to the band.
+    // ---- stage.  One wave-instruction moves `rpi` whole tile rows: lane = lr*cpr2 + cc, and the
+    // LDS image of those rows is exactly the lanes in order (what LDS-DMA requires).  Rows clamp
+    // to the band; halo columns outside the row are loaded from a clamped (don't-care) address.
     {
-        int row = t / cpr2, cc = t - row * cpr2;
-        const int drow = NT / cpr2, dcc = NT - drow * cpr2;
-        for (int i = t; i < nchunks; i += NT) {
-            const int sr = min(max(ty0 - R + row, 0), p.H - 1);
-            const int sc = min(max(x0c + cc - 1, 0), p.cpr - 1);
-            const uint8_t *g = img_in + (size_t)sr * (size_t)p.pitch + (size_t)sc * 16u;
-            if constexpr (DMA) {
-                // LDS destination = wave-uniform base + lane*16; lanes hold consecutive i.
-                uint8_t *base = lds + (size_t)(i - (t & 63)) * 16u;
-                __builtin_amdgcn_global_load_lds(
-                    (const void __attribute__((address_space(1))) *)g,
-                    (void __attribute__((address_space(3))) *)base, 16, 0, 0);
-            } else {
-                *reinterpret_cast<uint4 *>(lds + (size_t)i * 16u) = *reinterpret_cast<const uint4 *>(g);
+        const int lane = t & 63, wv = t >> 6, nwaves = NT >> 6;
+        const int rpi = 64 / cpr2;                    // >= 1
+        const int lr = lane / cpr2, cc = lane - lr * cpr2;
+        const bool act = lr < rpi;
+        const unsigned col_off = (unsigned)min(max(x0c + cc - 1, 0), p.cpr - 1) * 16u;
+        for (int u = wv; u * rpi < nrows; u += nwaves) {
+            const int row = u * rpi + lr;
+            if (act && row < nrows) {
+                const int sr = min(max(ty0 - R + row, 0), p.H - 1);
+                const uint8_t *g = img_in + ((unsigned)sr * (unsigned)p.pitch + col_off);
+                if constexpr (DMA) {
+                    uint8_t *base = lds + (size_t)(u * rpi * cpr2) * 16u;    // wave-uniform; + lane*16 by HW
+                    __builtin_amdgcn_global_load_lds(
+                        (const void __attribute__((address_space(1))) *)g,
+                        (void __attribute__((address_space(3))) *)base, 16, 0, 0);
+                } else {
+                    *reinterpret_cast<uint4 *>(lds + (size_t)(u * rpi * cpr2 + lane) * 16u) =
+                        *reinterpret_cast<const uint4 *>(g);
+                }
             }
-            row += drow; cc += dcc;
-            if (cc >= cpr2) { cc -= cpr2; row++; }
         }
         if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -209,37 +225,41 @@ __global__ __launch_bounds__(256) void blur_tiled_kernel(const TiledParams p)
     if (grp >= p.ngroups || r0 >= rows_out) return;   // no barrier below
     const bool at_start = (x0c + col) == 0;
     const bool at_end = (x0c + col) == p.cpr - 1;
+    const bool any_edge = __builtin_amdgcn_ballot_w64(at_start || at_end) != 0ull;
     const int lrow = cpr2 * 16;
     const uint8_t *lp = lds + ((size_t)r0 * cpr2 + (col + 1)) * 16u;
     uint8_t *op = p.out + (long long)img * p.out_stride +
                   (size_t)(ty0 - p.y0 + r0) * (size_t)p.pitch + (size_t)(x0c + col) * 16u;
 
     constexpr int WIN = 2 * R + 1;
-    u16x2 hw[WIN][8];
+    uint32_t hw[WIN][8];
 #pragma unroll
-    for (int k = 0; k < 2 * R; k++) hrow<C, R>(lp + k * lrow, at_start, at_end, hw[k]);
+    for (int k = 0; k < 2 * R; k++) hrow<C, R>(lp + k * lrow, any_edge, at_start, at_end, hw[k]);
 
 #pragma unroll
     for (int r = 0; r < RPG; r++) {
-        hrow<C, R>(lp + (r + 2 * R) * lrow, at_start, at_end, hw[(r + 2 * R) % WIN]);
-        u16x2 o[8];
+        hrow<C, R>(lp + (r + 2 * R) * lrow, any_edge, at_start, at_end, hw[(r + 2 * R) % WIN]);
+        uint32_t o[4];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
+        for (int i = 0; i < 4; i++) {
             if constexpr (R == 1) {
-                // (h0 + 2 h1 + h2) * 16: result byte = high byte of each u16 (max 65280)
-                o[j] = ((hw[r % WIN][j] + hw[(r + 2) % WIN][j]) << (unsigned short)4) +
-                       (hw[(r + 1) % WIN][j] << (unsigned short)5);
+                // s = h0 + 2 h1 + h2 (<= 4080 per field); byte = s >> 4; re-interleave even/odd
+                const uint32_t se = (hw[r % WIN][i] + hw[(r + 2) % WIN][i]) + (hw[(r + 1) % WIN][i] << 1);
+                const uint32_t so = (hw[r % WIN][4 + i] + hw[(r + 2) % WIN][4 + i]) + (hw[(r + 1) % WIN][4 + i] << 1);
+                o[i] = ((se >> 4) & EVEN_MASK) | ((so << 4) & ~EVEN_MASK);
             } else {
-                // h0 + 4 h1 + 6 h2 + 4 h3 + h4 (max 65280), >> 8 = high byte
-                o[j] = (hw[r % WIN][j] + hw[(r + 4) % WIN][j]) +
-                       ((hw[(r + 1) % WIN][j] + hw[(r + 3) % WIN][j]) << (unsigned short)2) +
-                       hw[(r + 2) % WIN][j] * (unsigned short)6;
+                // s = h0 + 4 h1 + 6 h2 + 4 h3 + h4 (<= 65280 per field); byte = s >> 8 = high byte
+                const uint32_t se = mad6(hw[(r + 2) % WIN][i],
+                                         ((hw[(r + 1) % WIN][i] + hw[(r + 3) % WIN][i]) << 2) +
+                                             (hw[r % WIN][i] + hw[(r + 4) % WIN][i]));
+                const uint32_t so = mad6(hw[(r + 2) % WIN][4 + i],
+                                         ((hw[(r + 1) % WIN][4 + i] + hw[(r + 3) % WIN][4 + i]) << 2) +
+                                             (hw[r % WIN][4 + i] + hw[(r + 4) % WIN][4 + i]));
+                o[i] = __builtin_amdgcn_perm(so, se, 0x07030501u);
             }
         }
         if (r0 + r < rows_out) {
-            uint4 v;
-            v.x = narrow_hi8(o[0], o[1]); v.y = narrow_hi8(o[2], o[3]);
-            v.z = narrow_hi8(o[4], o[5]); v.w = narrow_hi8(o[6], o[7]);
+            uint4 v; v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
             *reinterpret_cast<uint4 *>(op + (size_t)r * (size_t)p.pitch) = v;
         }
     }
@@ -293,7 +313,7 @@ Tunables &tunables()
     static Tunables t = [] {
         Tunables v{1, 8, 1};
         if (const char *e = getenv("MI_BLUR_STAGE")) v.stage_dma = strcmp(e, "reg") != 0;
-        if (const char *e = getenv("MI_BLUR_RPG")) v.rpg = atoi(e) == 16 ? 16 : 8;
+        if (const char *e = getenv("MI_BLUR_RPG")) { const int r = atoi(e); v.rpg = (r == 4 || r == 16) ? r : 8; }
         if (const char *e = getenv("MI_BLUR_XCD")) v.xcd_remap = atoi(e) != 0;
         return v;
     }();
@@ -326,6 +346,9 @@ static int launch_tiled_cr(const LaunchDesc &d, const TiledParams &p, dim3 grid,
     if (rpg == 16)
         return dma ? do_launch(blur_tiled_kernel<C, R, 16, true>, grid, block, lds, d, p)
                    : do_launch(blur_tiled_kernel<C, R, 16, false>, grid, block, lds, d, p);
+    if (rpg == 4)
+        return dma ? do_launch(blur_tiled_kernel<C, R, 4, true>, grid, block, lds, d, p)
+                   : do_launch(blur_tiled_kernel<C, R, 4, false>, grid, block, lds, d, p);
     return dma ? do_launch(blur_tiled_kernel<C, R, 8, true>, grid, block, lds, d, p)
                : do_launch(blur_tiled_kernel<C, R, 8, false>, grid, block, lds, d, p);
 }
@@ -354,7 +377,7 @@ static int launch_tiled(const LaunchDesc &d)
     p.in_stride = (long long)d.band_rows * pitch;
     p.out_stride = (long long)rows * pitch;
     p.pitch = pitch; p.cpr = cpr; p.H = d.band_rows; p.y0 = d.y0; p.y1 = d.y1;
-    p.nstrips = (cpr + 63) / 64;
+    p.nstrips = (cpr + 61) / 62;               // ncols + 2 halo chunks <= 64 lanes: one row per wave-instruction
     p.ncols = (cpr + p.nstrips - 1) / p.nstrips;
 
     // Row groups per tile: the most efficient split of the rows (fewest idle row slots

@@ -70,7 +70,7 @@ extern "C" int mi_blur_set_option(const char *key, int value)
     if (!key) return MI_BLUR_ERR_INVALID;
     Tunables &t = tunables();
     if (!strcmp(key, "stage_dma")) t.stage_dma = value != 0;
-    else if (!strcmp(key, "rows_per_thread")) { if (value != 8 && value != 16) return MI_BLUR_ERR_INVALID; t.rpg = value; }
+    else if (!strcmp(key, "rows_per_thread")) { if (value != 4 && value != 8 && value != 16) return MI_BLUR_ERR_INVALID; t.rpg = value; }
     else if (!strcmp(key, "xcd_remap")) t.xcd_remap = value != 0;
     else return MI_BLUR_ERR_INVALID;
     return MI_BLUR_OK;
@@ -144,6 +144,7 @@ struct mi_blur_ctx {
     int rr = 0;
     std::vector<TimedLaunch> ev_pool;
     size_t ev_used = 0;
+    uint64_t timed_launches = 0, timed_bytes_alg = 0;   // resident launches that carried timestamp events
     // CPU device
     std::vector<CpuJob *> cpu_jobs;
     bool is_cpu() const { return device == MI_BLUR_DEVICE_CPU; }
@@ -281,7 +282,17 @@ extern "C" int mi_blur_sync(mi_blur_ctx *c, mi_blur_timing *timing)
 
 extern "C" void mi_blur_reset_timing(mi_blur_ctx *c)
 {
-    if (c) c->tm = mi_blur_timing{};
+    if (!c) return;
+    c->tm = mi_blur_timing{};
+    c->timed_launches = 0; c->timed_bytes_alg = 0;
+}
+
+// For resident runs that time only every n-th launch: how many launches (and how many
+// algorithmic bytes) the accumulated kernel_ms covers.  Submit paths time every launch.
+extern "C" void mi_blur_timed_coverage(mi_blur_ctx *c, uint64_t *launches, uint64_t *bytes_alg)
+{
+    if (launches) *launches = c ? c->timed_launches : 0;
+    if (bytes_alg) *bytes_alg = c ? c->timed_bytes_alg : 0;
 }
 
 // Cleanup: heterogeneous_blur.c:727-744.
@@ -425,14 +436,16 @@ extern "C" void *mi_blur_resident_out(mi_blur_ctx *c) { return c ? c->pool_out :
 
 // One pass of the stream over the resident pool: the batch loop of
 // heterogeneous_blur.c:418-427 with the transfers gone (data already in HBM).
-extern "C" int mi_blur_resident_run(mi_blur_ctx *c, int n_images, int batch, int timed)
+extern "C" int mi_blur_resident_run(mi_blur_ctx *c, int n_images, int batch, int timed_every)
 {
     if (!c || n_images < 0 || batch <= 0) return MI_BLUR_ERR_INVALID;
     if (c->is_cpu() || !c->pool_in) return MI_BLUR_ERR_STATE;
     if (batch > c->pool_images) return MI_BLUR_ERR_INVALID;
     HIP_TRY(hipSetDevice(c->device));
-    for (int done = 0; done < n_images; done += batch) {
+    int launch_idx = 0;
+    for (int done = 0; done < n_images; done += batch, launch_idx++) {
         const int b = std::min(batch, n_images - done);
+        const bool timed = timed_every > 0 && launch_idx % timed_every == 0;
         if (c->cursor + b > c->pool_images) c->cursor = 0;
         Slot &s = c->slots[c->rr];
         c->rr = (c->rr + 1) % (int)c->slots.size();
@@ -455,6 +468,7 @@ extern "C" int mi_blur_resident_run(mi_blur_ctx *c, int n_images, int batch, int
         if (rc) return rc;
         c->cursor += b;
         c->tm.launches += 1;
+        if (timed) { c->timed_launches += 1; c->timed_bytes_alg += 2ull * c->image_bytes * (uint64_t)b; }
     }
     c->tm.images += (uint64_t)n_images;
     c->tm.bytes_alg += 2ull * c->image_bytes * (uint64_t)n_images;

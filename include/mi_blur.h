@@ -159,11 +159,14 @@ void *mi_blur_resident_out(mi_blur_ctx *ctx);
 /* One pass of the image stream over the resident pool: n_images images taken
  * cyclically from the pool, one launch per `batch` images (the last launch takes
  * the remainder, heterogeneous_blur.c:423-427).  Launches go round-robin over the
- * context's streams.  Kernel durations are taken per launch from the dispatch's
- * own start/stop timestamps (the HIP analogue of clGetEventProfilingInfo) when
- * timed != 0, and accumulate into the context's timing.  Asynchronous; follow
- * with mi_blur_sync. */
-int mi_blur_resident_run(mi_blur_ctx *ctx, int n_images, int batch, int timed);
+ * context's streams.  Every timed_every-th launch of the pass (0 = none, 1 = all)
+ * carries the dispatch's own start/stop timestamps (the HIP analogue of
+ * clGetEventProfilingInfo); their durations accumulate into the context's
+ * kernel_ms and mi_blur_timed_coverage says how many launches/bytes that covers.
+ * (Timestamped launches cost the host ~3x an ordinary launch, so a small-batch
+ * stream is sampled rather than timed in full.)  Asynchronous; follow with mi_blur_sync. */
+int mi_blur_resident_run(mi_blur_ctx *ctx, int n_images, int batch, int timed_every);
+void mi_blur_timed_coverage(mi_blur_ctx *ctx, uint64_t *launches, uint64_t *bytes_alg);
 
 /* ------------------------------------------------------------------------
  * CPU device kernel, exposed for the hosts' `cpu` mode and for timing the

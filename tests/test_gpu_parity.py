@@ -202,9 +202,10 @@ def test_resident_stream(pkg, L, O, torch_cuda):
     with pkg.Context(0, w, h, c, 1, max_batch=35, n_slots=3) as ctx:
         ctx.resident_alloc(pool)
         ctx.resident_fill_synthetic(0)
-        ctx.resident_run(250, 35, timed=True)         # 8 launches (7x35 + 5), wraps the 100-image pool
+        ctx.resident_run(250, 35, timed=2)         # 8 launches (7x35 + 5), wraps the 100-image pool
         tm = ctx.sync()
         assert tm["images"] == 250 and tm["launches"] == 8 and tm["kernel_ms"] > 0
+        assert ctx.timed_coverage() == (4, (35 * 3 + 35) * 2 * h * w * c)   # launches 0,2,4,6 of 7x35+5
         assert tm["bytes_alg"] == 250 * 2 * h * w * c
         out = np.zeros((pool, h, w, c), np.uint8)
         ctx.resident_download(0, out.ctypes.data, pool)
