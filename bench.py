@@ -115,7 +115,9 @@ def main() -> None:
     ap.add_argument("--time-every", type=int, default=16,
                     help="a1: every n-th launch of the timed region carries dispatch timestamp events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--extra", action="store_true",
+                    help="also measure (after the timed region) the one-launch, PCIe-inclusive and 1080p 5x5 points")
+    ap.add_argument("--no-extra", action="store_true", help="(default; kept for old command lines)")
     args = ap.parse_args()
 
     import numpy as np
@@ -190,7 +192,7 @@ def main() -> None:
                   "reference_published_on": "320x240x3, i7-12700 + UHD 770 (CPU+iGPU together)"}
 
         # ---- extras at N=1: PCIe-inclusive rate, one-launch (HBM-bound) point, hd5 point
-        if world == 1 and not args.no_extra and args.workload == "a1":
+        if world == 1 and args.extra and args.workload == "a1":
             ctx.reset_timing()
             for _ in range(3):
                 ctx.resident_run(per_gpu, per_gpu, timed=1)             # whole stream in ONE launch

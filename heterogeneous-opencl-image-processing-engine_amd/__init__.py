@@ -127,6 +127,8 @@ def lib() -> C.CDLL:
         "mi_blur_host_free": (None, [vp]),
         "mi_blur_submit": (i, [vp, u8p, u8p, i]),
         "mi_blur_submit_band": (i, [vp, u8p, u8p, i, i, i]),
+        "mi_blur_submit_bands": (i, [vp, u8p, u8p, i, C.c_size_t, i, i, i]),
+        "mi_blur_wait_oldest": (i, [vp]),
         "mi_blur_sync": (i, [vp, C.POINTER(Timing)]),
         "mi_blur_reset_timing": (None, [vp]),
         "mi_blur_resident_alloc": (i, [vp, i]),

@@ -1,0 +1,341 @@
+// heterogeneous_blur — Approach 1 (image-level distribution) host, MI355X-native.
+//
+//   heterogeneous_blur {cpu|gpu|both} [gpu_ratio] [batch]  [--image F | --synthetic | --size WxH] [--channels C]
+//                      [--ksize 3|5] [--images N] [--gpus G] [--slots S] [--threads T] [--resident]
+//                      [--verbose] [--csv FILE] [--save FILE]
+//
+// Same positional command line, banner and report sections as the reference host
+// (heterogeneous_blur.c:41-100 CLI, :406-601 batch loop, :609-724 report).  What changed:
+//   * the OpenCL plumbing (:140-403) is the C ABI of libmi_blur.so: one context per device,
+//     the `cpu` device is native host threads (ROCm has no OpenCL CPU device), the `gpu` device is
+//     1..G MI355X, each with its own HIP streams — images are independent, no collectives;
+//   * a batch is ONE launch per device (plus one DMA each way), not one Write/NDRange/Read per
+//     image (:502-533); the first n_cpu images of a batch go to the CPU device, the rest are split
+//     contiguously over the GPUs (:449-458,496);
+//   * batch buffers are pinned and rotate through `slots` sets, so batch n+1 is built and uploaded
+//     while batch n computes; the reference's per-batch malloc/free (:431-432,596-597) is hoisted,
+//     its per-batch stream construction (memcpy of the source image into every slot, :440-442)
+//     stays inside the timed region as in the reference.
+#include "host_common.h"
+
+using namespace host;
+
+struct Dev {
+    mi_blur_ctx *ctx = nullptr;
+    std::string name;
+    mi_blur_timing tm{};
+    std::vector<char> submitted;   // per batch: did this device get work?
+};
+
+int main(int argc, char **argv)
+{
+    // ---------------- configuration (heterogeneous_blur.c:41-100)
+    int mode = 0;                                 // 0 both, 1 cpu, 2 gpu
+    const char *input_filename = "./image_320x240.jpg";
+    int BATCH_SIZE = 500;
+    const int local_work_size = 16;
+    float gpu_ratio = 0.5f;
+
+    Options opt;
+    const int npos = parse_flags(argc, argv, opt);
+    const int NUM_IMAGES = opt.images;
+
+    if (npos > 1) {
+        if (strcmp(argv[1], "cpu") == 0) { mode = 1; printf("Mode: CPU ONLY\n"); }
+        else if (strcmp(argv[1], "gpu") == 0) { mode = 2; printf("Mode: GPU ONLY\n"); }
+        else if (strcmp(argv[1], "both") == 0) { mode = 0; printf("Mode: HETEROGENEOUS (CPU + GPU)\n"); }
+        else { printf("Usage: %s [cpu|gpu|both]\n", argv[0]); printf("Defaulting to heterogeneous mode.\n"); }
+    } else {
+        printf("Mode: HETEROGENEOUS (CPU + GPU) [default]\n");
+    }
+    if (npos > 2) {
+        gpu_ratio = atof(argv[2]);
+        if (gpu_ratio < 0.0f || gpu_ratio > 1.0f) {
+            printf("Warning: gpu_ratio must be between 0.0 and 1.0. Using 0.5\n");
+            gpu_ratio = 0.5f;
+        }
+    }
+    if (npos > 3) {
+        BATCH_SIZE = atoi(argv[3]);
+        if (BATCH_SIZE < 1 || BATCH_SIZE > NUM_IMAGES) {
+            printf("Warning: BATCH_SIZE must be between 1 and %d. Using 500\n", NUM_IMAGES);
+            BATCH_SIZE = 500;
+        }
+    }
+    if (BATCH_SIZE > NUM_IMAGES) BATCH_SIZE = NUM_IMAGES;
+    const int NUM_BATCHES = (NUM_IMAGES + BATCH_SIZE - 1) / BATCH_SIZE;
+    if (!opt.image.empty()) input_filename = opt.image.c_str();
+    if (opt.resident && mode != 2) { printf("Error: --resident needs mode gpu\n"); return -1; }
+
+    if (mode == 0) printf("GPU ratio: %.1f%% GPU, %.1f%% CPU\n", gpu_ratio * 100, (1 - gpu_ratio) * 100);
+    printf("========== HETEROGENEOUS CONFIGURATION ==========\n");
+    printf("Input file: %s\n", opt.synthetic ? "(synthetic)" : input_filename);
+    printf("Number of images in stream: %d\n", NUM_IMAGES);
+    printf("Batch size: %d images\n", BATCH_SIZE);
+    printf("Number of batches: %d\n", NUM_BATCHES);
+    printf("Work-group size: %dx%d\n", local_work_size, local_work_size);
+    printf("Execution mode : %d\n", mode);
+    printf("Blur kernel: %dx%d\n", opt.ksize, opt.ksize);
+    printf("================================================\n\n");
+
+    // ---------------- load original image (heterogeneous_blur.c:104-137)
+    Image img = load_image(input_filename, opt.syn_w, opt.syn_h, opt.syn_c, opt.synthetic);
+    const int width = img.width, height = img.height, channels = img.channels;
+    const int radius = opt.ksize == 3 ? 1 : 2;
+    printf("Original image loaded: %dx%d, %d channels\n", width, height, channels);
+    const size_t image_size = (size_t)width * height * channels;
+    printf("Size of one image: %zu bytes (%.2f KB)\n", image_size, image_size / 1024.0);
+    printf("Original image source: %s\n\n", img.source.c_str());
+    const uint8_t *original_image = img.px.data();
+
+    // ---------------- device discovery (heterogeneous_blur.c:140-212)
+    const int ngpu_visible = mi_blur_device_count();
+    int G = mode == 1 ? 0 : opt.gpus;
+    if (mode != 1 && (ngpu_visible < 1 || G < 1 || G > ngpu_visible)) {
+        printf("Error: Could not find %d GPU device(s) (%d visible)\n", G < 1 ? 1 : G, ngpu_visible);
+        return -1;
+    }
+    const int nslots = opt.slots;
+    Dev cpu;
+    std::vector<Dev> gpus(G);
+    if (mode != 2) {
+        mi_check(mi_blur_create(&cpu.ctx, MI_BLUR_DEVICE_CPU, width, height, channels, radius, BATCH_SIZE, nslots, opt.threads),
+                 "Failed to create CPU context");
+        const unsigned hc = std::thread::hardware_concurrency();
+        cpu.name = "host threads x" + std::to_string(opt.threads > 0 ? opt.threads : (int)(hc ? hc : 1));
+        printf("CPU device: %s\n", cpu.name.c_str());
+        cpu.submitted.assign(NUM_BATCHES, 0);
+    }
+    for (int g = 0; g < G; g++) {
+        mi_check(mi_blur_create(&gpus[g].ctx, g, width, height, channels, radius, BATCH_SIZE, nslots, 0),
+                 "Failed to create GPU context");
+        gpus[g].name = "HIP device " + std::to_string(g);
+        printf("GPU device: %s\n", gpus[g].name.c_str());
+        gpus[g].submitted.assign(NUM_BATCHES, 0);
+    }
+    printf("\nKernel objects created (code objects are embedded in libmi_blur.so; nothing is read from the CWD)\n\n");
+
+    // ---------------- buffers (heterogeneous_blur.c:330-357,431-437): pinned, `nslots` rotating sets
+    printf("Allocating device buffers...\n");
+    std::vector<uint8_t *> batch_input(nslots, nullptr), batch_output(nslots, nullptr);
+    if (!opt.resident) {
+        for (int s = 0; s < nslots; s++) {
+            batch_input[s] = (uint8_t *)mi_blur_host_alloc((size_t)BATCH_SIZE * image_size);
+            batch_output[s] = (uint8_t *)mi_blur_host_alloc((size_t)BATCH_SIZE * image_size);
+            if (!batch_input[s] || !batch_output[s]) { printf("Error: Failed to allocate batch memory\n"); return -1; }
+        }
+    } else {
+        // device-resident stream: each GPU holds its share of the stream in HBM before the clock starts
+        for (int g = 0; g < G; g++) {
+            long long b, e;
+            mi_blur_shard_range(NUM_IMAGES, g, G, &b, &e);
+            int pool = (int)(e - b);
+            if (pool < BATCH_SIZE) pool = BATCH_SIZE;
+            mi_check(mi_blur_resident_alloc(gpus[g].ctx, pool), "Failed to allocate resident pool");
+            std::vector<uint8_t> rep((size_t)std::min(pool, 64) * image_size);
+            for (int i = 0; i < std::min(pool, 64); i++) memcpy(rep.data() + (size_t)i * image_size, original_image, image_size);
+            for (int i = 0; i < pool; i += 64)
+                mi_check(mi_blur_resident_upload(gpus[g].ctx, i, rep.data(), std::min(64, pool - i)), "resident upload failed");
+        }
+    }
+    printf("Device buffers allocated\n\n");
+    printf("Global work size: %d x %d\n", (width + 15) / 16 * 16, (height + 15) / 16 * 16);
+    printf("Local work size: %d x %d\n\n", local_work_size, local_work_size);
+
+    // ---------------- batch processing (heterogeneous_blur.c:406-601)
+    printf("Starting batch processing of %d images in %d batches...\n\n", NUM_IMAGES, NUM_BATCHES);
+    int total_images_cpu = 0, total_images_gpu = 0;
+    std::vector<uint8_t> first_output;
+    const double time_start_total = get_time_ms();
+
+    if (opt.resident) {
+        for (int g = 0; g < G; g++) {
+            long long b, e;
+            mi_blur_shard_range(NUM_IMAGES, g, G, &b, &e);
+            mi_check(mi_blur_resident_run(gpus[g].ctx, (int)(e - b), BATCH_SIZE, 1), "resident run failed");
+            total_images_gpu += (int)(e - b);
+        }
+        for (int g = 0; g < G; g++) mi_check(mi_blur_sync(gpus[g].ctx, &gpus[g].tm), "GPU sync failed");
+    } else {
+        for (int batch = 0; batch < NUM_BATCHES; batch++) {
+            if (opt.verbose) printf("=== Processing Batch %d/%d ===\n", batch + 1, NUM_BATCHES);
+            const int batch_start = batch * BATCH_SIZE;
+            int batch_count = BATCH_SIZE;
+            if (batch_start + batch_count > NUM_IMAGES) batch_count = NUM_IMAGES - batch_start;
+            const int s = batch % nslots;
+            // the buffer set was last used by batch - nslots: wait for exactly those submits
+            if (batch >= nslots) {
+                if (cpu.ctx && cpu.submitted[batch - nslots]) mi_check(mi_blur_wait_oldest(cpu.ctx), "CPU wait failed");
+                for (auto &d : gpus) if (d.submitted[batch - nslots]) mi_check(mi_blur_wait_oldest(d.ctx), "GPU wait failed");
+                if (opt.save.size() && first_output.empty() && batch - nslots == 0)
+                    first_output.assign(batch_output[s], batch_output[s] + image_size);
+            }
+            // create batch image stream (contiguous) — heterogeneous_blur.c:439-442
+            for (int i = 0; i < batch_count; i++) memcpy(batch_input[s] + (size_t)i * image_size, original_image, image_size);
+
+            int num_images_cpu = 0, num_images_gpu = 0;
+            mi_blur_a1_partition(mode, batch_count, gpu_ratio, &num_images_cpu, &num_images_gpu);
+            total_images_cpu += num_images_cpu;
+            total_images_gpu += num_images_gpu;
+            if (opt.verbose) printf("  Batch work distribution: CPU=%d, GPU=%d\n", num_images_cpu, num_images_gpu);
+
+            // images [0, n_cpu) -> CPU device, the rest -> GPUs in contiguous shares (:496)
+            if (num_images_cpu > 0) {
+                mi_check(mi_blur_submit(cpu.ctx, batch_input[s], batch_output[s], num_images_cpu), "CPU submit failed");
+                cpu.submitted[batch] = 1;
+            }
+            for (int g = 0; g < G && num_images_gpu > 0; g++) {
+                long long b, e;
+                mi_blur_shard_range(num_images_gpu, g, G, &b, &e);
+                if (e <= b) continue;
+                const size_t off = (size_t)(num_images_cpu + b) * image_size;
+                mi_check(mi_blur_submit(gpus[g].ctx, batch_input[s] + off, batch_output[s] + off, (int)(e - b)), "GPU submit failed");
+                gpus[g].submitted[batch] = 1;
+            }
+            if (opt.verbose) printf("  Batch %d submitted.\n\n", batch + 1);
+        }
+        // clFinish on every queue (heterogeneous_blur.c:538-539)
+        if (cpu.ctx) mi_check(mi_blur_sync(cpu.ctx, &cpu.tm), "CPU sync failed");
+        for (auto &d : gpus) mi_check(mi_blur_sync(d.ctx, &d.tm), "GPU sync failed");
+        if (opt.save.size() && first_output.empty()) first_output.assign(batch_output[0], batch_output[0] + image_size);
+    }
+    const double time_end_total = get_time_ms();
+    const double time_total_processing = time_end_total - time_start_total;
+    printf("All batches finished!\n\n");
+    if (opt.save.size() && !first_output.empty()) {
+        save_one_image(opt.save.c_str(), first_output.data(), width, height, channels);
+        printf("Saved example output: %s\n\n", opt.save.c_str());
+    }
+
+    // ---------------- performance analysis (heterogeneous_blur.c:609-724)
+    double time_cpu_transfer_in = cpu.tm.h2d_ms, time_cpu_kernel = cpu.tm.kernel_ms, time_cpu_transfer_out = cpu.tm.d2h_ms;
+    double time_gpu_transfer_in = 0, time_gpu_kernel = 0, time_gpu_transfer_out = 0;
+    uint64_t gpu_bytes_alg = 0, gpu_launches = 0;
+    for (auto &d : gpus) {
+        time_gpu_transfer_in += d.tm.h2d_ms; time_gpu_kernel += d.tm.kernel_ms; time_gpu_transfer_out += d.tm.d2h_ms;
+        gpu_bytes_alg += d.tm.bytes_alg; gpu_launches += d.tm.launches;
+    }
+
+    printf("========== PERFORMANCE RESULTS ==========\n\n");
+    printf("BATCH SIZE : %d\n", BATCH_SIZE);
+    printf("1. OVERALL EXECUTION TIME\n");
+    printf("   Total wall-clock time: %.2f ms (%.2f seconds)\n", time_total_processing, time_total_processing / 1000.0);
+    printf("   Total images processed: %d\n\n", NUM_IMAGES);
+
+    double time_cpu_total = 0;
+    if (total_images_cpu > 0) {
+        time_cpu_total = time_cpu_transfer_in + time_cpu_kernel + time_cpu_transfer_out;
+        printf("2. CPU DEVICE (processed %d images)\n", total_images_cpu);
+        printf("   Total CPU time:        %.2f ms\n", time_cpu_total);
+        printf("   - Transfer IN:         %.2f ms (%.1f%%)\n", time_cpu_transfer_in, (time_cpu_transfer_in / time_cpu_total) * 100);
+        printf("   - Kernel execution:    %.2f ms (%.1f%%)\n", time_cpu_kernel, (time_cpu_kernel / time_cpu_total) * 100);
+        printf("   - Transfer OUT:        %.2f ms (%.1f%%)\n", time_cpu_transfer_out, (time_cpu_transfer_out / time_cpu_total) * 100);
+        printf("   Average per image:     %.2f ms\n\n", time_cpu_total / total_images_cpu);
+    }
+    double time_gpu_total = 0;
+    if (total_images_gpu > 0) {
+        time_gpu_total = time_gpu_transfer_in + time_gpu_kernel + time_gpu_transfer_out;
+        printf("3. GPU DEVICE (processed %d images)\n", total_images_gpu);
+        printf("   Total GPU time:        %.2f ms\n", time_gpu_total);
+        printf("   - Transfer IN:         %.2f ms (%.1f%%)\n", time_gpu_transfer_in, (time_gpu_transfer_in / time_gpu_total) * 100);
+        printf("   - Kernel execution:    %.2f ms (%.1f%%)\n", time_gpu_kernel, (time_gpu_kernel / time_gpu_total) * 100);
+        printf("   - Transfer OUT:        %.2f ms (%.1f%%)\n", time_gpu_transfer_out, (time_gpu_transfer_out / time_gpu_total) * 100);
+        printf("   Average per image:     %.3f ms\n", time_gpu_total / total_images_gpu);
+        if (G > 1)
+            for (int g = 0; g < G; g++)
+                printf("   - %s: %llu images, in %.2f / kernel %.2f / out %.2f ms\n", gpus[g].name.c_str(),
+                       (unsigned long long)gpus[g].tm.images, gpus[g].tm.h2d_ms, gpus[g].tm.kernel_ms, gpus[g].tm.d2h_ms);
+        printf("\n");
+    }
+    printf("====================\n");
+
+    double imbalance = 0, speedup_factor = 0;
+    if (total_images_cpu > 0 && total_images_gpu > 0) {
+        printf("4. DEVICE COMPARISON\n");
+        speedup_factor = time_cpu_total / time_gpu_total;
+        if (speedup_factor > 1.0) printf("   GPU is %.2fx FASTER than CPU\n", speedup_factor);
+        else printf("   CPU is %.2fx FASTER than GPU\n", 1.0 / speedup_factor);
+        printf("   CPU/GPU time ratio: %.2f\n\n", speedup_factor);
+
+        printf("5. WORKLOAD BALANCE\n");
+        imbalance = fabs(time_cpu_total - time_gpu_total) / fmax(time_cpu_total, time_gpu_total) * 100.0;
+        printf("   Workload imbalance: %.1f%%\n", imbalance);
+        if (time_cpu_total > time_gpu_total) printf("   CPU is the BOTTLENECK (%.2f ms slower)\n\n", time_cpu_total - time_gpu_total);
+        else printf("   GPU is the BOTTLENECK (%.2f ms slower)\n\n", time_gpu_total - time_cpu_total);
+
+        printf("6. BOTTLENECK IDENTIFICATION\n");
+        printf("   CPU bottleneck: ");
+        if (time_cpu_transfer_in + time_cpu_transfer_out > time_cpu_kernel)
+            printf("COMMUNICATION (%.1f%% of time)\n", ((time_cpu_transfer_in + time_cpu_transfer_out) / time_cpu_total) * 100);
+        else printf("COMPUTATION (%.1f%% of time)\n", (time_cpu_kernel / time_cpu_total) * 100);
+        printf("   GPU bottleneck: ");
+        if (time_gpu_transfer_in + time_gpu_transfer_out > time_gpu_kernel)
+            printf("COMMUNICATION (%.1f%% of time)\n", ((time_gpu_transfer_in + time_gpu_transfer_out) / time_gpu_total) * 100);
+        else printf("COMPUTATION (%.1f%% of time)\n", (time_gpu_kernel / time_gpu_total) * 100);
+    }
+    printf("\n");
+
+    printf("7. THROUGHPUT\n");
+    const double throughput_mpixels = ((double)NUM_IMAGES * width * height) / (time_total_processing / 1000.0) / 1000000.0;
+    const double img_per_sec = NUM_IMAGES / (time_total_processing / 1000.0);
+    printf("   Overall throughput: %.2f Megapixels/sec\n", throughput_mpixels);
+    printf("   Images per second: %.2f\n\n", img_per_sec);
+    printf("=========================================\n\n");
+
+    double optimal_gpu_ratio = 0;
+    if (total_images_cpu > 0 && total_images_gpu > 0) {
+        const double t_cpu_per_image = time_cpu_total / total_images_cpu;
+        const double t_gpu_per_image = time_gpu_total / total_images_gpu;
+        optimal_gpu_ratio = t_cpu_per_image / (t_cpu_per_image + t_gpu_per_image);
+        printf("8. OPTIMAL RATIO RECOMMENDATION\n");
+        printf("   Based on measured performance:\n");
+        printf("   CPU: %.3f ms/image\n", t_cpu_per_image);
+        printf("   GPU: %.3f ms/image\n", t_gpu_per_image);
+        printf("   Recommended GPU ratio: %.1f%%\n", optimal_gpu_ratio * 100);
+        printf("   Run with: ./heterogeneous_blur both %.3f\n\n", optimal_gpu_ratio);
+    }
+
+    // ---------------- MI355X addendum: kernel-only rate against the HBM roofline
+    double hbm_gbps = 0, roofline_frac = 0;
+    if (total_images_gpu > 0 && time_gpu_kernel > 0) {
+        hbm_gbps = (double)gpu_bytes_alg / (time_gpu_kernel / 1000.0) / 1e9 * G;   // kernel_ms is summed over G concurrent GPUs
+        roofline_frac = hbm_gbps / (HBM_PEAK_GBS * G);
+        printf("9. MI355X KERNEL ROOFLINE (%d GPU%s)\n", G, G > 1 ? "s" : "");
+        printf("   Launches: %llu (one per batch per GPU), avg %.2f us\n", (unsigned long long)gpu_launches,
+               time_gpu_kernel * 1000.0 / gpu_launches);
+        printf("   Algorithmic bytes (2*W*H*C per image): %.2f MB\n", gpu_bytes_alg / 1e6);
+        printf("   Kernel-only rate: %.0f images/sec, %.1f GB/s = %.1f%% of %.0f GB/s HBM peak\n",
+               total_images_gpu / (time_gpu_kernel / 1000.0) * G, hbm_gbps, roofline_frac * 100, HBM_PEAK_GBS * G);
+        if (!opt.resident)
+            printf("   Host link: %.1f GB/s in, %.1f GB/s out (sum over GPUs)\n",
+                   (double)total_images_gpu * image_size / (time_gpu_transfer_in / 1000.0) / 1e9 * G,
+                   (double)total_images_gpu * image_size / (time_gpu_transfer_out / 1000.0) / 1e9 * G);
+        printf("\n");
+    }
+
+    if (!opt.csv.empty()) {   // columns of data/approach2/approach2/per_run.csv + hbm_gbps, roofline_frac, n_gpus
+        FILE *f = fopen(opt.csv.c_str(), "a");
+        if (f) {
+            if (ftell(f) == 0)
+                fprintf(f, "batch_size_file,run,file,mode,gpu_ratio_cfg,cpu_ratio_cfg,images,batches,img_w,img_h,wg_w,wg_h,wall_ms,"
+                           "cpu_images,cpu_total_ms,cpu_in_ms,cpu_kernel_ms,cpu_out_ms,cpu_ms_per_img,gpu_images,gpu_total_ms,gpu_in_ms,"
+                           "gpu_kernel_ms,gpu_out_ms,gpu_ms_per_img,speedup_gpu_vs_cpu,imbalance_pct,bottleneck,bottleneck_delta_ms,"
+                           "mpix_per_sec,img_per_sec,recommended_gpu_ratio,batch_size_log,hbm_gbps,roofline_frac,n_gpus\n");
+            fprintf(f, "%d,1,,%d,%.3f,%.3f,%d,%d,%d,%d,16,16,%.2f,%d,%.2f,%.2f,%.2f,%.2f,%.4f,%d,%.2f,%.2f,%.2f,%.2f,%.4f,%.2f,%.1f,%s,%.2f,%.2f,%.2f,%.3f,%d,%.1f,%.4f,%d\n",
+                    BATCH_SIZE, mode, gpu_ratio, 1 - gpu_ratio, NUM_IMAGES, NUM_BATCHES, width, height, time_total_processing,
+                    total_images_cpu, time_cpu_total, time_cpu_transfer_in, time_cpu_kernel, time_cpu_transfer_out,
+                    total_images_cpu ? time_cpu_total / total_images_cpu : 0.0,
+                    total_images_gpu, time_gpu_total, time_gpu_transfer_in, time_gpu_kernel, time_gpu_transfer_out,
+                    total_images_gpu ? time_gpu_total / total_images_gpu : 0.0, speedup_factor, imbalance,
+                    time_cpu_total > time_gpu_total ? "CPU" : "GPU", fabs(time_cpu_total - time_gpu_total),
+                    throughput_mpixels, img_per_sec, optimal_gpu_ratio, BATCH_SIZE, hbm_gbps, roofline_frac, G);
+            fclose(f);
+        }
+    }
+
+    // ---------------- cleanup (heterogeneous_blur.c:727-747)
+    for (int s = 0; s < nslots; s++) { mi_blur_host_free(batch_input[s]); mi_blur_host_free(batch_output[s]); }
+    if (cpu.ctx) mi_blur_destroy(cpu.ctx);
+    for (auto &d : gpus) mi_blur_destroy(d.ctx);
+    return 0;
+}

@@ -1,0 +1,391 @@
+// split_image_blur — Approach 2 (split-image + halo) host, MI355X-native.
+//
+//   split_image_blur [gpu_ratio] [batch]  [--image F | --synthetic | --size WxH] [--channels C] [--ksize 3|5]
+//                    [--images N] [--gpus G] [--slots S] [--threads T] [--verbose] [--csv FILE] [--save FILE]
+//   split_image_blur --resident [--gpus G] [--size WxH] [--ksize 3|5] [--iters N]
+//
+// Default mode keeps the reference host's semantics (split_image_blur.c:62-102 CLI, :142-173
+// geometry, :441-607 batch loop, :615-721 report): every image is split at
+// split_row = (int)(H*(1-gpu_ratio)) clamped to [HALO, H-HALO]; the CPU device blurs rows
+// [0, split_row) from input rows [0, split_row+HALO), the GPU device(s) blur rows [split_row, H) from
+// input rows [split_row-HALO, H); each device runs the kernel on its own band with the band height as
+// `height` and the halo output rows are dropped (:401,414,526,537).  HALO = blur radius (1 for the
+// reference 3x3, :70).  Differences: the `cpu` device is native host threads; with --gpus G the GPU
+// rows are shared out over G GPUs (each with its own halos); a batch is ONE 2-D DMA in, ONE launch and
+// ONE 2-D DMA out per device (mi_blur_submit_bands) instead of a Write/NDRange/Read per image (:520-541).
+//
+// --resident is the multi-GPU form of the same idea for ONE large image (BASELINE config 5): the image
+// is row-sharded once into the GPUs' HBM; every iteration exchanges the `radius` boundary rows between
+// neighbouring GPUs with RCCL send/recv over xGMI (the reference re-uploads overlapping slices from the
+// host instead, :516,520,530) and blurs each shard.
+#include "host_common.h"
+
+using namespace host;
+
+struct Part {                      // one device's share of every image
+    mi_blur_ctx *ctx = nullptr;
+    std::string name;
+    int in_row0 = 0, band_rows = 0, halo_top = 0, halo_bottom = 0, out_row0 = 0, out_rows = 0;
+    mi_blur_timing tm{};
+};
+
+static int run_resident(const Options &opt);
+
+int main(int argc, char **argv)
+{
+    // ---------------- configuration (split_image_blur.c:62-102)
+    const char *input_filename = "./image_320x240.jpg";
+    int BATCH_SIZE = 500;
+    const int local_work_size = 16;
+    float gpu_ratio = 0.5f;
+
+    Options opt;
+    const int npos = parse_flags(argc, argv, opt);
+    if (opt.resident) return run_resident(opt);
+    const int NUM_IMAGES = opt.images;
+    const int HALO = opt.ksize == 3 ? 1 : 2;
+
+    if (npos > 1) {
+        gpu_ratio = atof(argv[1]);
+        if (gpu_ratio < 0.0f || gpu_ratio > 1.0f) {
+            printf("Warning: gpu_ratio must be between 0.0 and 1.0. Using 0.5\n");
+            gpu_ratio = 0.5f;
+        }
+    }
+    if (npos > 2) {
+        BATCH_SIZE = atoi(argv[2]);
+        if (BATCH_SIZE < 1 || BATCH_SIZE > NUM_IMAGES) {
+            printf("Warning: BATCH_SIZE must be between 1 and %d. Using 500\n", NUM_IMAGES);
+            BATCH_SIZE = 500;
+        }
+    }
+    if (BATCH_SIZE > NUM_IMAGES) BATCH_SIZE = NUM_IMAGES;
+    const int NUM_BATCHES = (NUM_IMAGES + BATCH_SIZE - 1) / BATCH_SIZE;
+    if (!opt.image.empty()) input_filename = opt.image.c_str();
+
+    printf("========== SPLIT-IMAGE CONFIGURATION ==========\n");
+    printf("Input file: %s\n", opt.synthetic ? "(synthetic)" : input_filename);
+    printf("Number of images in stream: %d\n", NUM_IMAGES);
+    printf("Batch size: %d images\n", BATCH_SIZE);
+    printf("Number of batches: %d\n", NUM_BATCHES);
+    printf("Work-group size: %dx%d\n", local_work_size, local_work_size);
+    printf("GPU ratio: %.1f%% (rows to GPU)\n", gpu_ratio * 100);
+    printf("Halo size: %d row(s)\n", HALO);
+    printf("================================================\n\n");
+
+    // ---------------- load original image (split_image_blur.c:106-139)
+    Image img = load_image(input_filename, opt.syn_w, opt.syn_h, opt.syn_c, opt.synthetic);
+    const int width = img.width, height = img.height, channels = img.channels;
+    printf("Original image loaded: %dx%d, %d channels\n", width, height, channels);
+    const size_t pitch = (size_t)width * channels, image_size = pitch * height;
+    printf("Size of one image: %zu bytes (%.2f KB)\n", image_size, image_size / 1024.0);
+    printf("Original image source: %s\n\n", img.source.c_str());
+    const uint8_t *original_image = img.px.data();
+    if (height < 2 * HALO + 1) { printf("Error: image too small for a %d-row halo split\n", HALO); return -1; }
+
+    // ---------------- split dimensions (split_image_blur.c:142-173)
+    mi_blur_a2_geometry geo;
+    {
+        int raw = (int)(height * (1.0f - gpu_ratio));
+        if (raw < HALO) printf("Warning: split_row too small, adjusting to %d\n", HALO);
+        if (raw > height - HALO) printf("Warning: split_row too large, adjusting to %d\n", height - HALO);
+    }
+    mi_blur_a2_split(height, gpu_ratio, HALO, &geo);
+    const int split_row = geo.split_row;
+    printf("Split configuration:\n");
+    printf("  Split row: %d (CPU: rows 0-%d, GPU: rows %d-%d)\n", split_row, split_row - 1, split_row, height - 1);
+    printf("  CPU: %d input rows (inc. halo), %d output rows\n", geo.cpu_input_rows, geo.cpu_output_rows);
+    printf("  GPU: %d input rows (inc. halo), %d output rows\n", geo.gpu_input_rows, geo.gpu_output_rows);
+    printf("  CPU input size: %.2f KB, output size: %.2f KB\n", pitch * geo.cpu_input_rows / 1024.0, pitch * geo.cpu_output_rows / 1024.0);
+    printf("  GPU input size: %.2f KB, output size: %.2f KB\n\n", pitch * geo.gpu_input_rows / 1024.0, pitch * geo.gpu_output_rows / 1024.0);
+
+    // ---------------- devices (split_image_blur.c:175-247): the reference needs BOTH devices
+    const int G = opt.gpus;
+    if (mi_blur_device_count() < 1 || G < 1 || G > mi_blur_device_count()) {
+        printf("Error: Could not find both CPU and GPU devices (%d GPU(s) visible, %d asked)\n", mi_blur_device_count(), G);
+        return -1;
+    }
+    const int nslots = opt.slots;
+    Part cpu;
+    cpu.in_row0 = 0; cpu.band_rows = geo.cpu_input_rows; cpu.halo_top = 0; cpu.halo_bottom = HALO;
+    cpu.out_row0 = 0; cpu.out_rows = geo.cpu_output_rows;
+    mi_check(mi_blur_create(&cpu.ctx, MI_BLUR_DEVICE_CPU, width, height, channels, HALO, BATCH_SIZE, nslots, opt.threads),
+             "Failed to create CPU context");
+    cpu.name = "host threads";
+    printf("CPU device: %s\n", cpu.name.c_str());
+    std::vector<Part> gpus(G);
+    for (int g = 0; g < G; g++) {
+        // GPU rows [split_row, H) shared out evenly; every share carries HALO rows from its neighbours
+        Part &p = gpus[g];
+        long long b, e;
+        mi_blur_shard_range(geo.gpu_output_rows, g, G, &b, &e);
+        p.out_row0 = split_row + (int)b; p.out_rows = (int)(e - b);
+        p.halo_top = HALO;                                             // row split_row-HALO.. exists (split_row >= HALO)
+        p.halo_bottom = std::min(HALO, height - (p.out_row0 + p.out_rows));
+        p.in_row0 = p.out_row0 - p.halo_top;
+        p.band_rows = p.out_rows + p.halo_top + p.halo_bottom;
+        if (p.out_rows <= 0) { printf("Error: more GPUs than GPU rows\n"); return -1; }
+        mi_check(mi_blur_create(&p.ctx, g, width, height, channels, HALO, BATCH_SIZE, nslots, 0), "Failed to create GPU context");
+        p.name = "HIP device " + std::to_string(g);
+        printf("GPU device: %s (rows %d-%d)\n", p.name.c_str(), p.out_row0, p.out_row0 + p.out_rows - 1);
+    }
+    printf("\nKernel objects created\n\n");
+
+    printf("Allocating device buffers...\n");
+    std::vector<uint8_t *> batch_input(nslots), batch_output(nslots);
+    for (int s = 0; s < nslots; s++) {
+        batch_input[s] = (uint8_t *)mi_blur_host_alloc((size_t)BATCH_SIZE * image_size);
+        batch_output[s] = (uint8_t *)mi_blur_host_alloc((size_t)BATCH_SIZE * image_size);
+        if (!batch_input[s] || !batch_output[s]) { printf("Error: Failed to allocate batch memory\n"); return -1; }
+    }
+    printf("Device buffers allocated\n\n");
+    printf("CPU global size: %d x %d\n", (width + 15) / 16 * 16, (geo.cpu_input_rows + 15) / 16 * 16);
+    printf("GPU global size: %d x %d\n", (width + 15) / 16 * 16, (geo.gpu_input_rows + 15) / 16 * 16);
+    printf("Local size: %d x %d\n\n", local_work_size, local_work_size);
+
+    // ---------------- batch processing (split_image_blur.c:441-607)
+    printf("Starting batch processing of %d images in %d batches...\n\n", NUM_IMAGES, NUM_BATCHES);
+    std::vector<uint8_t> first_output;
+    const double time_start_total = get_time_ms();
+    for (int batch = 0; batch < NUM_BATCHES; batch++) {
+        if (opt.verbose) printf("=== Processing Batch %d/%d ===\n", batch + 1, NUM_BATCHES);
+        const int batch_start = batch * BATCH_SIZE;
+        int batch_count = BATCH_SIZE;
+        if (batch_start + batch_count > NUM_IMAGES) batch_count = NUM_IMAGES - batch_start;
+        const int s = batch % nslots;
+        if (batch >= nslots) {                      // every device took part in every batch
+            mi_check(mi_blur_wait_oldest(cpu.ctx), "CPU wait failed");
+            for (auto &p : gpus) mi_check(mi_blur_wait_oldest(p.ctx), "GPU wait failed");
+            if (opt.save.size() && first_output.empty() && batch - nslots == 0)
+                first_output.assign(batch_output[s], batch_output[s] + image_size);
+        }
+        for (int i = 0; i < batch_count; i++) memcpy(batch_input[s] + (size_t)i * image_size, original_image, image_size);
+        if (opt.verbose) printf("  Processing %d images (each split between CPU and GPU)\n", batch_count);
+
+        // CPU: top rows of every image; GPU(s): bottom rows (split_image_blur.c:511-541), batched
+        mi_check(mi_blur_submit_bands(cpu.ctx, batch_input[s] + (size_t)cpu.in_row0 * pitch, batch_output[s] + (size_t)cpu.out_row0 * pitch,
+                                      batch_count, image_size, cpu.band_rows, cpu.halo_top, cpu.halo_bottom), "CPU submit failed");
+        for (auto &p : gpus)
+            mi_check(mi_blur_submit_bands(p.ctx, batch_input[s] + (size_t)p.in_row0 * pitch, batch_output[s] + (size_t)p.out_row0 * pitch,
+                                          batch_count, image_size, p.band_rows, p.halo_top, p.halo_bottom), "GPU submit failed");
+        if (opt.verbose) printf("  Batch %d submitted.\n\n", batch + 1);
+    }
+    mi_check(mi_blur_sync(cpu.ctx, &cpu.tm), "CPU sync failed");
+    for (auto &p : gpus) mi_check(mi_blur_sync(p.ctx, &p.tm), "GPU sync failed");
+    if (opt.save.size() && first_output.empty()) first_output.assign(batch_output[0], batch_output[0] + image_size);
+    const double time_end_total = get_time_ms();
+    const double time_total_processing = time_end_total - time_start_total;
+    printf("All batches finished!\n\n");
+    if (opt.save.size()) {
+        save_one_image(opt.save.c_str(), first_output.data(), width, height, channels);
+        printf("Saved example output: %s\n\n", opt.save.c_str());
+    }
+
+    // ---------------- performance analysis (split_image_blur.c:615-721)
+    const double time_cpu_transfer_in = cpu.tm.h2d_ms, time_cpu_kernel = cpu.tm.kernel_ms, time_cpu_transfer_out = cpu.tm.d2h_ms;
+    double time_gpu_transfer_in = 0, time_gpu_kernel = 0, time_gpu_transfer_out = 0;
+    uint64_t gpu_bytes_alg = 0, gpu_launches = 0;
+    for (auto &p : gpus) {
+        time_gpu_transfer_in += p.tm.h2d_ms; time_gpu_kernel += p.tm.kernel_ms; time_gpu_transfer_out += p.tm.d2h_ms;
+        gpu_bytes_alg += p.tm.bytes_alg; gpu_launches += p.tm.launches;
+    }
+    const int cpu_output_rows = geo.cpu_output_rows, gpu_output_rows = geo.gpu_output_rows;
+    printf("========== PERFORMANCE RESULTS ==========\n\n");
+    printf("BATCH SIZE : %d\n", BATCH_SIZE);
+    printf("1. OVERALL EXECUTION TIME\n");
+    printf("   Total wall-clock time: %.2f ms (%.2f seconds)\n", time_total_processing, time_total_processing / 1000.0);
+    printf("   Total images processed: %d\n\n", NUM_IMAGES);
+
+    const double time_cpu_total = time_cpu_transfer_in + time_cpu_kernel + time_cpu_transfer_out;
+    printf("2. CPU DEVICE (processed %d images - top %d rows each)\n", NUM_IMAGES, cpu_output_rows);
+    printf("   Total CPU time:        %.2f ms\n", time_cpu_total);
+    printf("   - Transfer IN:         %.2f ms (%.1f%%)\n", time_cpu_transfer_in, (time_cpu_transfer_in / time_cpu_total) * 100);
+    printf("   - Kernel execution:    %.2f ms (%.1f%%)\n", time_cpu_kernel, (time_cpu_kernel / time_cpu_total) * 100);
+    printf("   - Transfer OUT:        %.2f ms (%.1f%%)\n\n", time_cpu_transfer_out, (time_cpu_transfer_out / time_cpu_total) * 100);
+
+    const double time_gpu_total = time_gpu_transfer_in + time_gpu_kernel + time_gpu_transfer_out;
+    printf("3. GPU DEVICE (processed %d images - bottom %d rows each)\n", NUM_IMAGES, gpu_output_rows);
+    printf("   Total GPU time:        %.2f ms\n", time_gpu_total);
+    printf("   - Transfer IN:         %.2f ms (%.1f%%)\n", time_gpu_transfer_in, (time_gpu_transfer_in / time_gpu_total) * 100);
+    printf("   - Kernel execution:    %.2f ms (%.1f%%)\n", time_gpu_kernel, (time_gpu_kernel / time_gpu_total) * 100);
+    printf("   - Transfer OUT:        %.2f ms (%.1f%%)\n", time_gpu_transfer_out, (time_gpu_transfer_out / time_gpu_total) * 100);
+    if (G > 1)
+        for (auto &p : gpus)
+            printf("   - %s: rows %d-%d, in %.2f / kernel %.2f / out %.2f ms\n", p.name.c_str(), p.out_row0,
+                   p.out_row0 + p.out_rows - 1, p.tm.h2d_ms, p.tm.kernel_ms, p.tm.d2h_ms);
+    printf("\n============================\n");
+
+    printf("4. DEVICE COMPARISON\n");
+    const double speedup_factor = time_cpu_total / time_gpu_total;
+    if (speedup_factor > 1.0) printf("   GPU is %.2fx FASTER than CPU\n", speedup_factor);
+    else printf("   CPU is %.2fx FASTER than GPU\n", 1.0 / speedup_factor);
+    printf("   CPU/GPU time ratio: %.2f\n\n", speedup_factor);
+
+    printf("5. WORKLOAD BALANCE\n");
+    const double imbalance = fabs(time_cpu_total - time_gpu_total) / fmax(time_cpu_total, time_gpu_total) * 100.0;
+    printf("   Workload imbalance: %.1f%%\n", imbalance);
+    if (time_cpu_total > time_gpu_total) printf("   CPU is the BOTTLENECK (%.2f ms slower)\n\n", time_cpu_total - time_gpu_total);
+    else printf("   GPU is the BOTTLENECK (%.2f ms slower)\n\n", time_gpu_total - time_cpu_total);
+
+    printf("6. BOTTLENECK IDENTIFICATION\n");
+    printf("   CPU bottleneck: ");
+    if (time_cpu_transfer_in + time_cpu_transfer_out > time_cpu_kernel)
+        printf("COMMUNICATION (%.1f%% of time)\n", ((time_cpu_transfer_in + time_cpu_transfer_out) / time_cpu_total) * 100);
+    else printf("COMPUTATION (%.1f%% of time)\n", (time_cpu_kernel / time_cpu_total) * 100);
+    printf("   GPU bottleneck: ");
+    if (time_gpu_transfer_in + time_gpu_transfer_out > time_gpu_kernel)
+        printf("COMMUNICATION (%.1f%% of time)\n", ((time_gpu_transfer_in + time_gpu_transfer_out) / time_gpu_total) * 100);
+    else printf("COMPUTATION (%.1f%% of time)\n", (time_gpu_kernel / time_gpu_total) * 100);
+    printf("\n");
+
+    printf("7. THROUGHPUT\n");
+    const double throughput_mpixels = ((double)NUM_IMAGES * width * height) / (time_total_processing / 1000.0) / 1000000.0;
+    const double img_per_sec = NUM_IMAGES / (time_total_processing / 1000.0);
+    printf("   Overall throughput: %.2f Megapixels/sec\n", throughput_mpixels);
+    printf("   Images per second: %.2f\n\n", img_per_sec);
+    printf("=========================================\n\n");
+
+    printf("8. SPLIT-IMAGE STATISTICS\n");
+    printf("   CPU time per image: %.3f ms (for %d rows)\n", time_cpu_total / NUM_IMAGES, cpu_output_rows);
+    printf("   GPU time per image: %.3f ms (for %d rows)\n", time_gpu_total / NUM_IMAGES, gpu_output_rows);
+    printf("   Combined time per image: %.3f ms\n", time_total_processing / NUM_IMAGES);
+    printf("   Current GPU ratio: %.1f%%\n\n", gpu_ratio * 100);
+
+    const double cpu_time_per_row = time_cpu_total / ((double)NUM_IMAGES * cpu_output_rows);
+    const double gpu_time_per_row = time_gpu_total / ((double)NUM_IMAGES * gpu_output_rows);
+    const double optimal_gpu_ratio = cpu_time_per_row / (cpu_time_per_row + gpu_time_per_row);
+    printf("9. OPTIMAL RATIO RECOMMENDATION\n");
+    printf("   CPU: %.5f ms/row\n", cpu_time_per_row);
+    printf("   GPU: %.5f ms/row\n", gpu_time_per_row);
+    printf("   Recommended GPU ratio: %.1f%%\n", optimal_gpu_ratio * 100);
+    printf("   Run with: ./split_image_blur %.3f\n\n", optimal_gpu_ratio);
+
+    double hbm_gbps = 0, roofline_frac = 0;
+    if (time_gpu_kernel > 0) {
+        hbm_gbps = (double)gpu_bytes_alg / (time_gpu_kernel / 1000.0) / 1e9 * G;
+        roofline_frac = hbm_gbps / (HBM_PEAK_GBS * G);
+        printf("10. MI355X KERNEL ROOFLINE (%d GPU%s)\n", G, G > 1 ? "s" : "");
+        printf("   Launches: %llu, avg %.2f us; algorithmic bytes %.2f MB\n", (unsigned long long)gpu_launches,
+               time_gpu_kernel * 1000.0 / gpu_launches, gpu_bytes_alg / 1e6);
+        printf("   Kernel-only: %.1f GB/s = %.1f%% of %.0f GB/s HBM peak\n\n", hbm_gbps, roofline_frac * 100, HBM_PEAK_GBS * G);
+    }
+
+    if (!opt.csv.empty()) {
+        FILE *f = fopen(opt.csv.c_str(), "a");
+        if (f) {
+            if (ftell(f) == 0)
+                fprintf(f, "batch_size_file,run,file,mode,gpu_ratio_cfg,cpu_ratio_cfg,images,batches,img_w,img_h,wg_w,wg_h,wall_ms,"
+                           "cpu_images,cpu_total_ms,cpu_in_ms,cpu_kernel_ms,cpu_out_ms,cpu_ms_per_img,gpu_images,gpu_total_ms,gpu_in_ms,"
+                           "gpu_kernel_ms,gpu_out_ms,gpu_ms_per_img,speedup_gpu_vs_cpu,imbalance_pct,bottleneck,bottleneck_delta_ms,"
+                           "mpix_per_sec,img_per_sec,recommended_gpu_ratio,batch_size_log,hbm_gbps,roofline_frac,n_gpus\n");
+            fprintf(f, "%d,1,,split,%.3f,%.3f,%d,%d,%d,%d,16,16,%.2f,%d,%.2f,%.2f,%.2f,%.2f,%.4f,%d,%.2f,%.2f,%.2f,%.2f,%.4f,%.2f,%.1f,%s,%.2f,%.2f,%.2f,%.3f,%d,%.1f,%.4f,%d\n",
+                    BATCH_SIZE, gpu_ratio, 1 - gpu_ratio, NUM_IMAGES, NUM_BATCHES, width, height, time_total_processing,
+                    NUM_IMAGES, time_cpu_total, time_cpu_transfer_in, time_cpu_kernel, time_cpu_transfer_out, time_cpu_total / NUM_IMAGES,
+                    NUM_IMAGES, time_gpu_total, time_gpu_transfer_in, time_gpu_kernel, time_gpu_transfer_out, time_gpu_total / NUM_IMAGES,
+                    speedup_factor, imbalance, time_cpu_total > time_gpu_total ? "CPU" : "GPU", fabs(time_cpu_total - time_gpu_total),
+                    throughput_mpixels, img_per_sec, optimal_gpu_ratio, BATCH_SIZE, hbm_gbps, roofline_frac, G);
+            fclose(f);
+        }
+    }
+
+    for (int s = 0; s < nslots; s++) { mi_blur_host_free(batch_input[s]); mi_blur_host_free(batch_output[s]); }
+    mi_blur_destroy(cpu.ctx);
+    for (auto &p : gpus) mi_blur_destroy(p.ctx);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// --resident: ONE large image, row shards resident in G GPUs, RCCL halo exchange per iteration.
+// Uses the HIP runtime directly only for device memory and streams (hipMalloc/hipMemcpy/hipStream);
+// kernels and the exchange go through the C ABI.
+// ------------------------------------------------------------------------------------------------
+#include <hip/hip_runtime.h>
+
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%d - %s\n", (int)e_, hipGetErrorString(e_)); exit(-1); } } while (0)
+
+static int run_resident(const Options &opt)
+{
+    const int G = opt.gpus, radius = opt.ksize == 3 ? 1 : 2;
+    const int W = opt.size_given ? opt.syn_w : 8192, H = opt.size_given ? opt.syn_h : 8192, C = opt.syn_c;
+    const size_t pitch = (size_t)W * C;
+    if (mi_blur_device_count() < G || G < 1) { printf("Error: %d GPU(s) asked, %d visible\n", G, mi_blur_device_count()); return -1; }
+    if (H / G < radius) { printf("Error: shards of %d rows are thinner than the halo\n", H / G); return -1; }
+    printf("========== SPLIT-IMAGE (RESIDENT, MULTI-GPU) ==========\n");
+    printf("Image: %dx%d, %d channels (%.2f MB), %dx%d blur, %d GPU(s), %d iterations\n", W, H, C, pitch * H / 1e6, opt.ksize,
+           opt.ksize, G, opt.iters);
+    printf("Halo: %d row(s) = %zu bytes per neighbour per direction, RCCL send/recv\n\n", radius, radius * pitch);
+
+    std::vector<uint8_t> image(pitch * H);
+    mi_blur_fill_synthetic(image.data(), W, H, C, 0, 1, 0);
+    std::vector<mi_blur_band> band(G);
+    std::vector<uint8_t *> d_band(G), d_out(G);
+    std::vector<hipStream_t> stream(G);
+    std::vector<int> owned(G), devs(G);
+    for (int g = 0; g < G; g++) {
+        devs[g] = g;
+        mi_blur_band_of(H, radius, g, G, &band[g]);
+        owned[g] = band[g].row_end - band[g].row_begin;
+        const size_t rows = owned[g] + band[g].halo_top + band[g].halo_bottom;
+        HIP_OK(hipSetDevice(g));
+        HIP_OK(hipStreamCreateWithFlags(&stream[g], hipStreamNonBlocking));
+        HIP_OK(hipMalloc((void **)&d_band[g], rows * pitch));
+        HIP_OK(hipMalloc((void **)&d_out[g], (size_t)owned[g] * pitch));
+        HIP_OK(hipMemset(d_band[g], 0, rows * pitch));
+        // upload OWNED rows only: the halo rows arrive from the neighbours over xGMI
+        HIP_OK(hipMemcpy(d_band[g] + (size_t)band[g].halo_top * pitch, image.data() + (size_t)band[g].row_begin * pitch,
+                         (size_t)owned[g] * pitch, hipMemcpyHostToDevice));
+        printf("GPU %d: rows %d-%d (+%d/+%d halo)\n", g, band[g].row_begin, band[g].row_end - 1, band[g].halo_top, band[g].halo_bottom);
+    }
+    std::vector<mi_blur_comm *> comm(G, nullptr);
+    mi_check(mi_blur_comm_init_all(comm.data(), G, devs.data()), "RCCL communicator init failed");
+
+    auto step = [&]() {
+        std::vector<void *> st(G);
+        for (int g = 0; g < G; g++) st[g] = stream[g];
+        mi_check(mi_blur_halo_exchange_all(comm.data(), G, d_band.data(), W, C, owned.data(), radius, st.data()), "halo exchange failed");
+        for (int g = 0; g < G; g++) {
+            HIP_OK(hipSetDevice(g));
+            mi_check(mi_blur_enqueue_band(d_band[g], d_out[g], W, owned[g] + band[g].halo_top + band[g].halo_bottom, C, radius,
+                                          band[g].halo_top, band[g].halo_top + owned[g], stream[g]), "band launch failed");
+        }
+    };
+    auto sync_all = [&]() { for (int g = 0; g < G; g++) { HIP_OK(hipSetDevice(g)); HIP_OK(hipStreamSynchronize(stream[g])); } };
+    step(); sync_all();                                  // warm-up (also first RCCL connection set-up)
+    const double t0 = get_time_ms();
+    for (int i = 0; i < opt.iters; i++) step();
+    sync_all();
+    const double ms = get_time_ms() - t0;
+
+    // verify against the single-device blur of the whole image on GPU 0
+    std::vector<uint8_t> got(pitch * H), want(pitch * H);
+    for (int g = 0; g < G; g++) {
+        HIP_OK(hipSetDevice(g));
+        HIP_OK(hipMemcpy(got.data() + (size_t)band[g].row_begin * pitch, d_out[g], (size_t)owned[g] * pitch, hipMemcpyDeviceToHost));
+    }
+    {
+        HIP_OK(hipSetDevice(0));
+        uint8_t *di, *dout;
+        HIP_OK(hipMalloc((void **)&di, pitch * H)); HIP_OK(hipMalloc((void **)&dout, pitch * H));
+        HIP_OK(hipMemcpy(di, image.data(), pitch * H, hipMemcpyHostToDevice));
+        mi_check(mi_blur_enqueue(di, dout, W, H, C, radius, 1, nullptr), "whole-image launch failed");
+        HIP_OK(hipDeviceSynchronize());
+        HIP_OK(hipMemcpy(want.data(), dout, pitch * H, hipMemcpyDeviceToHost));
+        HIP_OK(hipFree(di)); HIP_OK(hipFree(dout));
+    }
+    const bool same = memcmp(got.data(), want.data(), pitch * H) == 0;
+    printf("\nSharded result %s the single-device blur (fnv %016llx)\n", same ? "EQUALS" : "DIFFERS FROM",
+           (unsigned long long)mi_blur_fnv1a64(got.data(), got.size()));
+    printf("\n========== PERFORMANCE RESULTS ==========\n");
+    printf("   Total wall-clock time: %.2f ms for %d iterations (%.3f ms per image)\n", ms, opt.iters, ms / opt.iters);
+    printf("   Images per second: %.2f\n", opt.iters / (ms / 1000.0));
+    printf("   Overall throughput: %.2f Megapixels/sec\n", (double)opt.iters * W * H / (ms / 1000.0) / 1e6);
+    const double gbps = 2.0 * pitch * H * opt.iters / (ms / 1000.0) / 1e9;
+    printf("   Algorithmic bandwidth (incl. exchange + launch gaps): %.1f GB/s = %.1f%% of %d x %.0f GB/s\n", gbps,
+           gbps / (HBM_PEAK_GBS * G) * 100, G, HBM_PEAK_GBS);
+    for (int g = 0; g < G; g++) {
+        HIP_OK(hipSetDevice(g));
+        mi_blur_comm_destroy(comm[g]);
+        HIP_OK(hipFree(d_band[g])); HIP_OK(hipFree(d_out[g])); HIP_OK(hipStreamDestroy(stream[g]));
+    }
+    return same ? 0 : 1;
+}

@@ -61,11 +61,12 @@ void cpu_blur_rows(const uint8_t *in, uint8_t *out, int W, int H, int C, int R, 
 // n_images bands of band_rows rows; output rows [y0,y1) of each.  Threads take whole
 // images when there are enough of them, else row slices of each image.
 void cpu_blur_batch(const uint8_t *in, uint8_t *out, int W, int band_rows, int C, int R, int n_images,
-                    int y0, int y1, int n_threads)
+                    int y0, int y1, int n_threads, size_t in_stride, size_t out_stride)
 {
     if (n_images <= 0) return;
     if (n_threads <= 0) n_threads = hardware_threads();
-    const size_t in_stride = (size_t)W * C * band_rows, out_stride = (size_t)W * C * (y1 - y0);
+    if (in_stride == 0) in_stride = (size_t)W * C * band_rows;
+    if (out_stride == 0) out_stride = (size_t)W * C * (y1 - y0);
     const int rows = y1 - y0;
     // work items: (image, row slice)
     int slices = 1;

@@ -118,7 +118,8 @@ struct Slot {
     hipEvent_t ks = nullptr, ke = nullptr;                     // kernel dispatch start/stop
     bool busy = false;
     uint8_t *user_out = nullptr;
-    size_t in_bytes = 0, out_bytes = 0;
+    size_t out_bytes = 0, out_band = 0, out_stride = 0;   // pending read-back: out_n bands of out_band bytes
+    int out_n = 0;
     bool out_staged = false;
 };
 
@@ -235,7 +236,8 @@ static int finish_slot(mi_blur_ctx *c, Slot &s)
 {
     if (!s.busy) return MI_BLUR_OK;
     HIP_TRY(hipStreamSynchronize(s.stream));
-    if (s.out_staged) memcpy(s.user_out, s.h_out, s.out_bytes);
+    if (s.out_staged)
+        for (int i = 0; i < s.out_n; i++) memcpy(s.user_out + (size_t)i * s.out_stride, s.h_out + (size_t)i * s.out_band, s.out_band);
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) c->tm.h2d_ms += ms;
     if (hipEventElapsedTime(&ms, s.ks, s.ke) == hipSuccess) c->tm.kernel_ms += ms;
@@ -312,20 +314,26 @@ extern "C" void mi_blur_destroy(mi_blur_ctx *c)
     delete c;
 }
 
-// One band/batch through a slot: Write -> NDRange -> Read (heterogeneous_blur.c:520-533),
-// but one launch for the whole batch instead of one per image.
+// One batch through a slot: Write -> NDRange -> Read (heterogeneous_blur.c:520-533), but one
+// launch (and one DMA each way) for the whole batch instead of one triple per image.
+// in_stride/out_stride: bytes between consecutive images' first band row / first output row in
+// HOST memory (a strided batch = Approach 2's "same rows of every image": a 2-D DMA gathers
+// the bands into one contiguous device batch).
 static int submit_common(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_out, int band_rows, int n_images,
-                         int y0, int y1)
+                         int y0, int y1, size_t in_stride, size_t out_stride)
 {
     const size_t pitch = (size_t)c->W * c->C;
-    const size_t in_bytes = pitch * band_rows * n_images, out_bytes = pitch * (size_t)(y1 - y0) * n_images;
+    const size_t band_in = pitch * band_rows, band_out = pitch * (size_t)(y1 - y0);
+    const size_t in_bytes = band_in * n_images, out_bytes = band_out * n_images;
+    if (in_stride == 0) in_stride = band_in;
+    if (out_stride == 0) out_stride = band_out;
     if (c->is_cpu()) {
         CpuJob *j = new (std::nothrow) CpuJob;
         if (!j) return MI_BLUR_ERR_NOMEM;
         const int W = c->W, C = c->C, R = c->R, nt = c->n_threads;
         j->th = std::thread([=]() {
             const auto t0 = std::chrono::steady_clock::now();
-            cpu_blur_batch(host_in, host_out, W, band_rows, C, R, n_images, y0, y1, nt);
+            cpu_blur_batch(host_in, host_out, W, band_rows, C, R, n_images, y0, y1, nt, in_stride, out_stride);
             j->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         });
         c->cpu_jobs.push_back(j);
@@ -335,12 +343,20 @@ static int submit_common(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_o
         c->next_slot = (c->next_slot + 1) % (int)c->slots.size();
         int rc = finish_slot(c, s);
         if (rc) return rc;
-        const uint8_t *src = host_in;
-        if (!is_pinned(host_in)) { memcpy(s.h_in, host_in, in_bytes); src = s.h_in; }
+        const bool in_pinned = is_pinned(host_in);
         s.out_staged = !is_pinned(host_out);
-        s.user_out = host_out; s.in_bytes = in_bytes; s.out_bytes = out_bytes;
+        s.user_out = host_out; s.out_bytes = out_bytes; s.out_band = band_out; s.out_stride = out_stride; s.out_n = n_images;
+        const uint8_t *src = host_in;
+        size_t src_stride = in_stride;
+        if (!in_pinned) {                       // pageable caller memory: gather into the slot's pinned staging
+            for (int i = 0; i < n_images; i++) memcpy(s.h_in + (size_t)i * band_in, host_in + (size_t)i * in_stride, band_in);
+            src = s.h_in; src_stride = band_in;
+        }
         HIP_TRY(hipEventRecord(s.ev[0], s.stream));
-        HIP_TRY(hipMemcpyAsync(s.d_in, src, in_bytes, hipMemcpyHostToDevice, s.stream));
+        if (src_stride == band_in)
+            HIP_TRY(hipMemcpyAsync(s.d_in, src, in_bytes, hipMemcpyHostToDevice, s.stream));
+        else
+            HIP_TRY(hipMemcpy2DAsync(s.d_in, band_in, src, src_stride, band_in, (size_t)n_images, hipMemcpyHostToDevice, s.stream));
         HIP_TRY(hipEventRecord(s.ev[1], s.stream));
         LaunchDesc d{};
         d.in = s.d_in; d.out = s.d_out; d.width = c->W; d.band_rows = band_rows; d.channels = c->C;
@@ -349,7 +365,10 @@ static int submit_common(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_o
         rc = launch(d);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(s.ev[2], s.stream));
-        HIP_TRY(hipMemcpyAsync(s.out_staged ? s.h_out : host_out, s.d_out, out_bytes, hipMemcpyDeviceToHost, s.stream));
+        if (s.out_staged || out_stride == band_out)
+            HIP_TRY(hipMemcpyAsync(s.out_staged ? s.h_out : host_out, s.d_out, out_bytes, hipMemcpyDeviceToHost, s.stream));
+        else
+            HIP_TRY(hipMemcpy2DAsync(host_out, out_stride, s.d_out, band_out, band_out, (size_t)n_images, hipMemcpyDeviceToHost, s.stream));
         HIP_TRY(hipEventRecord(s.ev[3], s.stream));
         s.busy = true;
         c->tm.bytes_h2d += in_bytes; c->tm.bytes_d2h += out_bytes;
@@ -365,7 +384,7 @@ extern "C" int mi_blur_submit(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *h
     if (!c || !host_in || !host_out || host_in == host_out) return MI_BLUR_ERR_INVALID;
     if (n_images < 0 || n_images > c->max_batch) return MI_BLUR_ERR_INVALID;
     if (n_images == 0) return MI_BLUR_OK;
-    return submit_common(c, host_in, host_out, c->H, n_images, 0, c->H);
+    return submit_common(c, host_in, host_out, c->H, n_images, 0, c->H, 0, 0);
 }
 
 extern "C" int mi_blur_submit_band(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_out, int band_rows,
@@ -374,7 +393,43 @@ extern "C" int mi_blur_submit_band(mi_blur_ctx *c, const uint8_t *host_in, uint8
     if (!c || !host_in || !host_out || host_in == host_out) return MI_BLUR_ERR_INVALID;
     if (band_rows <= 0 || band_rows > c->H || halo_top < 0 || halo_bottom < 0) return MI_BLUR_ERR_INVALID;
     if (halo_top + halo_bottom >= band_rows) return MI_BLUR_ERR_INVALID;
-    return submit_common(c, host_in, host_out, band_rows, 1, halo_top, band_rows - halo_bottom);
+    return submit_common(c, host_in, host_out, band_rows, 1, halo_top, band_rows - halo_bottom, 0, 0);
+}
+
+extern "C" int mi_blur_submit_bands(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_out, int n_images,
+                                    size_t host_image_stride, int band_rows, int halo_top, int halo_bottom)
+{
+    if (!c || !host_in || !host_out || host_in == host_out) return MI_BLUR_ERR_INVALID;
+    if (n_images < 0 || n_images > c->max_batch) return MI_BLUR_ERR_INVALID;
+    if (band_rows <= 0 || band_rows > c->H || halo_top < 0 || halo_bottom < 0) return MI_BLUR_ERR_INVALID;
+    if (halo_top + halo_bottom >= band_rows) return MI_BLUR_ERR_INVALID;
+    if (host_image_stride < (size_t)c->W * c->C * band_rows) return MI_BLUR_ERR_INVALID;
+    if (n_images == 0) return MI_BLUR_OK;
+    return submit_common(c, host_in, host_out, band_rows, n_images, halo_top, band_rows - halo_bottom,
+                         host_image_stride, host_image_stride);
+}
+
+// Wait for the OLDEST submit still in flight (its output is then in caller memory), so a host
+// that rotates n_slots batch buffers can refill the oldest one while the newer ones run.
+extern "C" int mi_blur_wait_oldest(mi_blur_ctx *c)
+{
+    if (!c) return MI_BLUR_ERR_INVALID;
+    if (c->is_cpu()) {
+        if (c->cpu_jobs.empty()) return MI_BLUR_OK;
+        CpuJob *j = c->cpu_jobs.front();
+        j->th.join();
+        c->tm.kernel_ms += j->ms;
+        delete j;
+        c->cpu_jobs.erase(c->cpu_jobs.begin());
+        return MI_BLUR_OK;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    const int n = (int)c->slots.size();
+    for (int i = 0; i < n; i++) {
+        Slot &s = c->slots[(c->next_slot + i) % n];
+        if (s.busy) return finish_slot(c, s);
+    }
+    return MI_BLUR_OK;
 }
 
 // ----------------------------------------------------------------------------------

@@ -140,6 +140,19 @@ int mi_blur_submit(mi_blur_ctx *ctx, const uint8_t *host_in, uint8_t *host_out, 
 int mi_blur_submit_band(mi_blur_ctx *ctx, const uint8_t *host_in, uint8_t *host_out,
                         int band_rows, int halo_top, int halo_bottom);
 
+/* Approach 2 for a whole batch: the SAME band (rows [r, r+band_rows) incl. halos) of n_images
+ * images that lie host_image_stride bytes apart in caller memory (the contiguous batch stream
+ * of split_image_blur.c:469-480).  host_in points at the band's first row in image 0, host_out
+ * at the band's first OUTPUT row in image 0 (same stride).  One 2-D DMA gathers the bands, one
+ * launch blurs them, one 2-D DMA scatters the interior rows back — instead of the reference's
+ * per-image Write/NDRange/Read on each device (:520-541). */
+int mi_blur_submit_bands(mi_blur_ctx *ctx, const uint8_t *host_in, uint8_t *host_out, int n_images,
+                         size_t host_image_stride, int band_rows, int halo_top, int halo_bottom);
+
+/* Block until the OLDEST submit still in flight has finished (its output is in caller memory).
+ * Lets a host rotate n_slots batch buffers: refill the oldest while the newer ones run. */
+int mi_blur_wait_oldest(mi_blur_ctx *ctx);
+
 /* clFinish + event harvest (heterogeneous_blur.c:538-579).  timing may be NULL. */
 int mi_blur_sync(mi_blur_ctx *ctx, mi_blur_timing *timing);
 void mi_blur_reset_timing(mi_blur_ctx *ctx);

@@ -1,0 +1,135 @@
+"""The C++ hosts keep the reference command lines and report sections
+(heterogeneous_blur.c:41-100,609-724; split_image_blur.c:62-102,615-721).
+CPU-only cases run here; cases that need a GPU carry the gpu marker."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def apps(pkg):
+    pkg.build_native()
+    a = os.path.join(pkg.APPS, "heterogeneous_blur")
+    b = os.path.join(pkg.APPS, "split_image_blur")
+    assert os.path.exists(a) and os.path.exists(b)
+    return a, b
+
+
+def run(cmd, cwd):
+    return subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, timeout=600)
+
+
+def write_ppm(path, img):
+    h, w, c = img.shape
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (w, h) if c == 3 else b"P5\n%d %d\n255\n" % (w, h))
+        f.write(img.tobytes())
+
+
+def read_ppm(path):
+    with open(path, "rb") as f:
+        magic = f.readline().strip()
+        w, h = map(int, f.readline().split())
+        assert f.readline().strip() == b"255"
+        c = 3 if magic == b"P6" else 1
+        return np.frombuffer(f.read(), np.uint8).reshape(h, w, c)
+
+
+A1_SECTIONS = ["========== HETEROGENEOUS CONFIGURATION ==========", "Number of images in stream:", "Batch size:",
+               "Number of batches:", "Work-group size: 16x16", "Execution mode :", "Original image loaded:",
+               "Size of one image:", "Starting batch processing of", "All batches finished!",
+               "========== PERFORMANCE RESULTS ==========", "1. OVERALL EXECUTION TIME", "Total wall-clock time:",
+               "Total images processed:", "7. THROUGHPUT", "Overall throughput:", "Images per second:"]
+
+
+def test_a1_cpu_mode_report_and_pixels(apps, O, tmp_path):
+    """`heterogeneous_blur cpu` (BASELINE config 0): plumbing without a GPU; output pixels == oracle."""
+    het, _ = apps
+    img = O.lcg_image(48, 64, 3)
+    write_ppm(tmp_path / "in.ppm", img)
+    r = run([het, "cpu", "0.5", "35", "--image", "in.ppm", "--images", "100", "--save", "out.ppm", "--csv", "run.csv"], tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for s in A1_SECTIONS + ["Mode: CPU ONLY", "Batch size: 35 images", "Number of batches: 3", "Execution mode : 1",
+                            "2. CPU DEVICE (processed 100 images)", "Original image loaded: 64x48, 3 channels"]:
+        assert s in r.stdout, s
+    assert "3. GPU DEVICE" not in r.stdout and "4. DEVICE COMPARISON" not in r.stdout     # heterogeneous_blur.c:638,654
+    assert np.array_equal(read_ppm(tmp_path / "out.ppm"), O.blur(img, 1))
+    rows = open(tmp_path / "run.csv").read().splitlines()
+    assert rows[0].startswith("batch_size_file,run,file,mode,") and rows[0].endswith("hbm_gbps,roofline_frac,n_gpus")
+    assert len(rows) == 2 and rows[1].split(",")[6] == "100"
+
+
+def test_a1_argument_handling_matches_reference(apps, tmp_path):
+    het, _ = apps
+    r = run([het, "cpu", "1.5", "99999", "--images", "40", "--size", "32x16"], tmp_path)
+    assert r.returncode == 0
+    assert "Warning: gpu_ratio must be between 0.0 and 1.0. Using 0.5" in r.stdout          # :72-75
+    assert "Warning: BATCH_SIZE must be between 1 and 40. Using 500" in r.stdout            # :80-83
+    r = run([het, "sideways", "--images", "10", "--size", "32x16"], tmp_path)
+    assert "Usage:" in r.stdout and "Defaulting to heterogeneous mode." in r.stdout           # :63-64
+
+
+def test_a1_ksize5_cpu(apps, O, tmp_path):
+    het, _ = apps
+    img = O.lcg_image(40, 48, 3)
+    write_ppm(tmp_path / "in.ppm", img)
+    r = run([het, "cpu", "0.5", "7", "--image", "in.ppm", "--images", "20", "--ksize", "5", "--save", "out.ppm"], tmp_path)
+    assert r.returncode == 0, r.stdout
+    assert np.array_equal(read_ppm(tmp_path / "out.ppm"), O.blur(img, 2))
+
+
+def test_gpu_modes_fail_loudly_without_gpu(apps, L, tmp_path):
+    if L.mi_blur_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    het, spl = apps
+    r = run([het, "gpu", "1.0", "35", "--images", "10", "--size", "32x16"], tmp_path)
+    assert r.returncode != 0 and "Error: Could not find" in r.stdout                          # :181-184
+    r = run([spl, "0.837", "35", "--images", "10", "--size", "32x16"], tmp_path)
+    assert r.returncode != 0 and "Error: Could not find both CPU and GPU devices" in r.stdout
+
+
+@pytest.mark.gpu
+def test_a1_gpu_and_both_modes(apps, O, tmp_path):
+    het, _ = apps
+    img = O.lcg_image(240, 320, 3)
+    write_ppm(tmp_path / "in.ppm", img)
+    want = O.blur(img, 1)
+    r = run([het, "gpu", "1.0", "35", "--image", "in.ppm", "--images", "500", "--save", "gpu.ppm"], tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for s in A1_SECTIONS + ["Mode: GPU ONLY", "3. GPU DEVICE (processed 500 images)", "9. MI355X KERNEL ROOFLINE"]:
+        assert s in r.stdout, s
+    assert np.array_equal(read_ppm(tmp_path / "gpu.ppm"), want)
+    r = run([het, "both", "0.728", "35", "--image", "in.ppm", "--images", "500", "--save", "both.ppm"], tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for s in ["Mode: HETEROGENEOUS (CPU + GPU)", "GPU ratio: 72.8% GPU, 27.2% CPU", "2. CPU DEVICE (processed 143 images)",
+              "3. GPU DEVICE (processed 357 images)", "4. DEVICE COMPARISON", "5. WORKLOAD BALANCE",
+              "6. BOTTLENECK IDENTIFICATION", "8. OPTIMAL RATIO RECOMMENDATION", "Run with: ./heterogeneous_blur both"]:
+        assert s in r.stdout, s      # 500 images / 35: 14 x (10 cpu + 25 gpu) + last batch of 10 -> (3 cpu, 7 gpu)
+    assert np.array_equal(read_ppm(tmp_path / "both.ppm"), want)
+    r = run([het, "gpu", "1.0", "35", "--size", "256x256", "--images", "5000", "--resident"], tmp_path)
+    assert r.returncode == 0 and "9. MI355X KERNEL ROOFLINE" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_a2_split_host(apps, O, tmp_path):
+    _, spl = apps
+    img = O.lcg_image(240, 320, 3)
+    write_ppm(tmp_path / "in.ppm", img)
+    r = run([spl, "0.837", "35", "--image", "in.ppm", "--images", "200", "--save", "split.ppm"], tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for s in ["========== SPLIT-IMAGE CONFIGURATION ==========", "GPU ratio: 83.7% (rows to GPU)", "Halo size: 1 row(s)",
+              "Split row: 39 (CPU: rows 0-38, GPU: rows 39-239)", "CPU: 40 input rows (inc. halo), 39 output rows",
+              "GPU: 202 input rows (inc. halo), 201 output rows", "2. CPU DEVICE (processed 200 images - top 39 rows each)",
+              "3. GPU DEVICE (processed 200 images - bottom 201 rows each)", "4. DEVICE COMPARISON", "5. WORKLOAD BALANCE",
+              "6. BOTTLENECK IDENTIFICATION", "7. THROUGHPUT", "8. SPLIT-IMAGE STATISTICS", "9. OPTIMAL RATIO RECOMMENDATION",
+              "Run with: ./split_image_blur"]:
+        assert s in r.stdout, s      # geometry lines as in data/approach2/35_run_1.txt:16-20
+    assert np.array_equal(read_ppm(tmp_path / "split.ppm"), O.blur(img, 1))
+    r = run([spl, "0.5", "16", "--image", "in.ppm", "--images", "64", "--ksize", "5", "--save", "split5.ppm"], tmp_path)
+    assert r.returncode == 0 and "Halo size: 2 row(s)" in r.stdout
+    assert np.array_equal(read_ppm(tmp_path / "split5.ppm"), O.blur(img, 2))
+    # resident row-shard mode on one GPU (no exchange partner: both image edges clamp)
+    r = run([spl, "--resident", "--gpus", "1", "--size", "2048x1024", "--iters", "5"], tmp_path)
+    assert r.returncode == 0 and "EQUALS the single-device blur" in r.stdout, r.stdout + r.stderr

@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /root/repo
 export TMPDIR=/tmp
 # 1. kernel trace + stats of the judged command
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py > $OUT/bench_under_trace.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_trace.json 2> $OUT/trace.err
 echo "trace rc=$?"
 # 2. PMC passes (separate runs, counters only + kernel-trace): HBM traffic of the headline workload
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $OUT/bench_fetch.json 2> $OUT/fetch.err
