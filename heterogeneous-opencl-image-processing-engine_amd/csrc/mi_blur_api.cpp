@@ -70,7 +70,7 @@ extern "C" int mi_blur_set_option(const char *key, int value)
     if (!key) return MI_BLUR_ERR_INVALID;
     Tunables &t = tunables();
     if (!strcmp(key, "stage_dma")) t.stage_dma = value != 0;
-    else if (!strcmp(key, "rows_per_thread")) { if (value != 4 && value != 8 && value != 16) return MI_BLUR_ERR_INVALID; t.rpg = value; }
+    else if (!strcmp(key, "rows_per_thread")) { if (value != 0 && value != 4 && value != 8 && value != 16) return MI_BLUR_ERR_INVALID; t.rpg = value; }
     else if (!strcmp(key, "xcd_remap")) t.xcd_remap = value != 0;
     else return MI_BLUR_ERR_INVALID;
     return MI_BLUR_OK;

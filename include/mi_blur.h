@@ -61,7 +61,7 @@ int mi_blur_version(void);
 
 /* Kernel tuning knobs (A/B benching and tests; defaults are the shipped configuration):
  *   "stage_dma"        1 = stage LDS tiles with global_load_lds (default), 0 = through VGPRs
- *   "rows_per_thread"  8 (default) | 16 output rows per thread of the tiled kernel
+ *   "rows_per_thread"  0 (default: chosen per launch from the grid size) | 4 | 8 | 16 output rows per thread
  *   "xcd_remap"        1 = XCD-contiguous blockIdx->tile map (default), 0 = identity */
 int mi_blur_set_option(const char *key, int value);
 

@@ -41,7 +41,7 @@ def gpu_blur(pkg, L, torch, host, radius, variant=0, y0=None, y1=None, opts=None
 
 def reset_opts(L):
     L.mi_blur_set_option(b"stage_dma", 1)
-    L.mi_blur_set_option(b"rows_per_thread", 8)
+    L.mi_blur_set_option(b"rows_per_thread", 0)
     L.mi_blur_set_option(b"xcd_remap", 1)
 
 
@@ -83,7 +83,8 @@ def test_tiled_kernel_bit_exact(pkg, L, O, torch_cuda, h, w, c, radius):
         reset_opts(L)
 
 
-@pytest.mark.parametrize("opts", [{"stage_dma": 1, "rows_per_thread": 16}, {"stage_dma": 0, "rows_per_thread": 8}])
+@pytest.mark.parametrize("opts", [{"stage_dma": 1, "rows_per_thread": 16}, {"stage_dma": 0, "rows_per_thread": 8},
+                                  {"stage_dma": 1, "rows_per_thread": 4}, {"stage_dma": 0, "rows_per_thread": 4, "xcd_remap": 0}])
 @pytest.mark.parametrize("radius", [1, 2])
 def test_tiled_kernel_option_cross(pkg, L, O, torch_cuda, opts, radius):
     try:
