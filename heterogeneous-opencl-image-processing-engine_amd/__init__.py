@@ -25,7 +25,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 DEVICE_CPU = -1
-VARIANT_AUTO, VARIANT_GENERIC, VARIANT_TILED = 0, 1, 2
+VARIANT_AUTO, VARIANT_GENERIC, VARIANT_TILED, VARIANT_STREAM = 0, 1, 2, 3
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_NOMEM, ERR_STATE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 UNIQUE_ID_BYTES = 128
 

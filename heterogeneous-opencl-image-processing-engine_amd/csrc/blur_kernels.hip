@@ -43,6 +43,7 @@
 #include "../../include/mi_blur.h"
 
 #include <hip/hip_ext.h>
+#include <type_traits>
 #include <limits.h>
 #include <stdlib.h>
 #include <string.h>
@@ -53,6 +54,8 @@ namespace mi_blur {
 // device helpers
 // ----------------------------------------------------------------------------------
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 as_pk(uint32_t x) { return __builtin_bit_cast(u16x2, x); }
 __device__ __forceinline__ uint32_t as_u32(u16x2 x) { return __builtin_bit_cast(uint32_t, x); }
 
@@ -127,6 +130,9 @@ __device__ __forceinline__ uint32_t hsum(const uint32_t (&Ew)[8], const uint32_t
 // Horizontal pass of one staged LDS row for this thread's chunk:
 // h[0..3] = even-byte sums of chunk dwords 0..3, h[4..7] = odd-byte sums.
 template <int C, int R>
+__device__ __forceinline__ void hrow_window(uint32_t (&w)[8], bool any_edge, bool at_start, bool at_end, uint32_t (&h)[8]);
+
+template <int C, int R>
 __device__ __forceinline__ void hrow(const uint8_t *lp, bool any_edge, bool at_start, bool at_end, uint32_t (&h)[8])
 {
     uint32_t w[8];
@@ -134,6 +140,13 @@ __device__ __forceinline__ void hrow(const uint8_t *lp, bool any_edge, bool at_s
     const uint4 c = *reinterpret_cast<const uint4 *>(lp);
     const uint2 b = *reinterpret_cast<const uint2 *>(lp + 16);
     w[0] = a.x; w[1] = a.y; w[2] = c.x; w[3] = c.y; w[4] = c.z; w[5] = c.w; w[6] = b.x; w[7] = b.y;
+    hrow_window<C, R>(w, any_edge, at_start, at_end, h);
+}
+
+// Same, from a register window w[0..7] = row-stream bytes [-8, 24) around the chunk.
+template <int C, int R>
+__device__ __forceinline__ void hrow_window(uint32_t (&w)[8], bool any_edge, bool at_start, bool at_end, uint32_t (&h)[8])
+{
     if (any_edge) {   // wave-uniform: some lane's chunk starts or ends the image row
         w[1] = at_start ? __builtin_amdgcn_perm(0u, w[2], sel_left(C, 1)) : w[1];
         w[0] = at_start ? __builtin_amdgcn_perm(0u, w[2], sel_left(C, 2)) : w[0];
@@ -159,6 +172,8 @@ struct TiledParams {
     int TH, ntiles_y, ngroups;        // output rows per tile, row tiles per image, row groups per tile
     unsigned nblocks;
     int xcd;
+    int debug_copy;                   // ablation only: skip the arithmetic, store the staged centre chunk
+    int nt_load, nt_store;            // non-temporal cache policy on the staging loads / the output stores
 };
 
 // ----------------------------------------------------------------------------------
@@ -206,9 +221,14 @@ __global__ __launch_bounds__(256) void blur_tiled_kernel(const TiledParams p)
                 const uint8_t *g = img_in + ((unsigned)sr * (unsigned)p.pitch + col_off);
                 if constexpr (DMA) {
                     uint8_t *base = lds + (size_t)(u * rpi * cpr2) * 16u;    // wave-uniform; + lane*16 by HW
-                    __builtin_amdgcn_global_load_lds(
-                        (const void __attribute__((address_space(1))) *)g,
-                        (void __attribute__((address_space(3))) *)base, 16, 0, 0);
+                    if (p.nt_load)      // aux = 2: non-temporal (streamed-once) cache policy
+                        __builtin_amdgcn_global_load_lds(
+                            (const void __attribute__((address_space(1))) *)g,
+                            (void __attribute__((address_space(3))) *)base, 16, 0, 2);
+                    else
+                        __builtin_amdgcn_global_load_lds(
+                            (const void __attribute__((address_space(1))) *)g,
+                            (void __attribute__((address_space(3))) *)base, 16, 0, 0);
                 } else {
                     *reinterpret_cast<uint4 *>(lds + (size_t)(u * rpi * cpr2 + lane) * 16u) =
                         *reinterpret_cast<const uint4 *>(g);
@@ -231,6 +251,17 @@ __global__ __launch_bounds__(256) void blur_tiled_kernel(const TiledParams p)
     uint8_t *op = p.out + (long long)img * p.out_stride +
                   (size_t)(ty0 - p.y0 + r0) * (size_t)p.pitch + (size_t)(x0c + col) * 16u;
 
+    if (p.debug_copy) {   // ablation: the load -> LDS -> store skeleton without the stencil arithmetic
+#pragma unroll
+        for (int r = 0; r < RPG; r++)
+            if (r0 + r < rows_out) {
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(lp + (r + R) * lrow);
+                if (p.nt_store) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(op + (size_t)r * (size_t)p.pitch));
+                else *reinterpret_cast<u32x4 *>(op + (size_t)r * (size_t)p.pitch) = v;
+            }
+        return;
+    }
+
     constexpr int WIN = 2 * R + 1;
     uint32_t hw[WIN][8];
 #pragma unroll
@@ -243,10 +274,12 @@ __global__ __launch_bounds__(256) void blur_tiled_kernel(const TiledParams p)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             if constexpr (R == 1) {
-                // s = h0 + 2 h1 + h2 (<= 4080 per field); byte = s >> 4; re-interleave even/odd
-                const uint32_t se = (hw[r % WIN][i] + hw[(r + 2) % WIN][i]) + (hw[(r + 1) % WIN][i] << 1);
-                const uint32_t so = (hw[r % WIN][4 + i] + hw[(r + 2) % WIN][4 + i]) + (hw[(r + 1) % WIN][4 + i] << 1);
-                o[i] = ((se >> 4) & EVEN_MASK) | ((so << 4) & ~EVEN_MASK);
+                // s = h0 + 2 h1 + h2 (<= 4080 per field).  16*s (<= 65280) still fits the field and puts the
+                // output byte s>>4 in the field's HIGH byte: v_lshl_add + v_add_lshl per parity, then one
+                // v_perm re-interleaves even/odd high bytes into the output dword.
+                const uint32_t se = (((hw[(r + 1) % WIN][i] << 1) + hw[r % WIN][i]) + hw[(r + 2) % WIN][i]) << 4;
+                const uint32_t so = (((hw[(r + 1) % WIN][4 + i] << 1) + hw[r % WIN][4 + i]) + hw[(r + 2) % WIN][4 + i]) << 4;
+                o[i] = __builtin_amdgcn_perm(so, se, 0x07030501u);
             } else {
                 // s = h0 + 4 h1 + 6 h2 + 4 h3 + h4 (<= 65280 per field); byte = s >> 8 = high byte
                 const uint32_t se = mad6(hw[(r + 2) % WIN][i],
@@ -259,10 +292,163 @@ __global__ __launch_bounds__(256) void blur_tiled_kernel(const TiledParams p)
             }
         }
         if (r0 + r < rows_out) {
-            uint4 v; v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
-            *reinterpret_cast<uint4 *>(op + (size_t)r * (size_t)p.pitch) = v;
+            u32x4 v; v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
+            if (p.nt_store) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(op + (size_t)r * (size_t)p.pitch));
+            else *reinterpret_cast<u32x4 *>(op + (size_t)r * (size_t)p.pitch) = v;
         }
     }
+}
+
+// ----------------------------------------------------------------------------------
+// streaming kernel: wave-private LDS row ring, no barrier — every wave is an independent stream
+// ----------------------------------------------------------------------------------
+// Lanes are consecutive 16-byte chunks of the flattened (image, band, chunk-column) space, so all 64 lanes
+// are busy whatever the row length.  A wave marches down its band of BH output rows.  Input rows arrive by
+// LDS-DMA (global_load_lds_dwordx4, 16 B/lane, coalesced) into a ring of STREAM_D row slots in the wave's
+// own LDS region, STREAM_P rows ahead of the row being consumed; a second 2-lane DMA brings the two
+// 16-byte chunks beyond the wave's span (the 1-pixel halo) for lanes 0 and 63.  Consuming a row is the
+// same 8+16+8-byte LDS read and even/odd SWAR horizontal pass as the tiled kernel, with a 2R+1-row
+// sliding window of sums in registers.  No barrier: a wave only reads what it loaded itself, ordered by
+// its own counted s_waitcnt vmcnt(N) (vmcnt is in issue order; every step issues exactly 2 DMAs + 1
+// store — a store that is not wanted gets an out-of-range buffer offset and is dropped by the range check).
+// The band's 2R halo rows are re-read through L2 (2R/BH extra L2->CU traffic).
+constexpr int STREAM_P = 6;                    // rows in flight ahead of the consumer
+constexpr int STREAM_D = 8;                    // ring slots: a slot is refilled two steps after it was read
+constexpr int STREAM_ROWB = 32 + 64 * 16;      // [left halo chunk][right halo chunk][64 chunks]
+
+struct StreamParams {
+    const uint8_t *in;
+    uint8_t *out;
+    long long in_stride, out_stride;
+    long long total;                  // n_images * nbands * cpr lanes of work
+    long long total_images;
+    int pitch, cpr;
+    int H, y0, y1;
+    int BH, nbands;
+    unsigned nblocks;
+    int xcd;
+};
+
+struct StreamLane { unsigned col, band; long long img; };
+__device__ __forceinline__ StreamLane stream_decode(unsigned f, const StreamParams &p)
+{
+    StreamLane l;
+    l.col = f % (unsigned)p.cpr;
+    const unsigned t2 = f / (unsigned)p.cpr;
+    l.band = t2 % (unsigned)p.nbands;
+    l.img = (long long)(t2 / (unsigned)p.nbands);
+    return l;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int C, int R>
+__global__ __launch_bounds__(256) void blur_stream_kernel(const StreamParams p)
+{
+    constexpr int WIN = 2 * R + 1, P = STREAM_P, D = STREAM_D, ROWB = STREAM_ROWB;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint8_t *ring = lds + wave * (D * ROWB);
+    const unsigned ring_off = (unsigned)(unsigned long long)((__attribute__((address_space(3))) uint8_t *)ring);   // LDS byte address
+
+    unsigned B = blockIdx.x;
+    if (p.xcd) {
+        const unsigned n = p.nblocks, q = n >> 3, r = n & 7u, x = B & 7u, k = B >> 3;
+        B = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+    }
+    const unsigned last = (unsigned)p.total - 1u;                       // host keeps total < 2^31
+    const unsigned f0 = (B * 4u + (unsigned)wave) * 64u;
+    const unsigned f_raw = f0 + (unsigned)lane;
+    const bool valid = f_raw <= last;
+    const unsigned f = valid ? f_raw : last;                            // dead lanes still run on valid addresses; no stores
+    const StreamLane me = stream_decode(f, p);
+    // lanes 0 / 1 also fetch the chunk left of the wave's span / right of it (flat neighbours; unused at row edges)
+    const unsigned fe = lane == 0 ? (f0 > 0 ? f0 - 1u : 0u) : min(f0 + 64u, last);
+    const StreamLane he = stream_decode(fe, p);
+
+    const int row0 = p.y0 + (int)me.band * p.BH, row0e = p.y0 + (int)he.band * p.BH;
+    const int rows_out = valid ? min(p.BH, p.y1 - row0) : 0;
+    const bool at_start = me.col == 0, at_end = (int)me.col == p.cpr - 1;
+    const bool any_edge = __builtin_amdgcn_ballot_w64(at_start || at_end) != 0ull;
+    const uint8_t *gsrc = p.in + me.img * p.in_stride + (size_t)me.col * 16u;
+    const uint8_t *gsrc_e = p.in + he.img * p.in_stride + (size_t)he.col * 16u;
+
+    const long long img0 = __builtin_amdgcn_readfirstlane((int)me.img);
+    const long long out_left = p.out_stride * (p.total_images - img0);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
+        p.out + img0 * p.out_stride, 0, (int)(unsigned)(out_left > 0xffffffffLL ? 0xffffffffLL : out_left), 0x00020000);
+    const unsigned OOB = 0xffffffffu;
+    const unsigned dst_off = (unsigned)((me.img - img0) * p.out_stride) + (unsigned)(row0 - p.y0) * (unsigned)p.pitch + me.col * 16u;
+
+    // per-lane LDS offsets inside a ring slot: centre chunk, the 8 bytes before it, the 8 bytes after it
+    const int oc = 32 + lane * 16;
+    const int ol = lane == 0 ? 8 : oc - 8;           // lane 0: tail of the left halo chunk
+    const int orr = lane == 63 ? 16 : oc + 16;       // lane 63: head of the right halo chunk
+
+    auto issue_row = [&](int j) {                    // j-th input row of the band (band row row0 - R + j), clamped to the band
+        uint8_t *slot = ring + (j % D) * ROWB;       // wave-uniform
+        const uint8_t *g = gsrc + (size_t)min(max(row0 - R + j, 0), p.H - 1) * (size_t)p.pitch;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)g,
+                                         (void __attribute__((address_space(3))) *)(slot + 32), 16, 0, 0);
+        if (lane < 2) {
+            const uint8_t *ge = gsrc_e + (size_t)min(max(row0e - R + j, 0), p.H - 1) * (size_t)p.pitch;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)ge,
+                                             (void __attribute__((address_space(3))) *)slot, 16, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < P; j++) issue_row(j);
+
+    uint32_t hw[WIN][8] = {};
+    const int niter = (p.BH + 2 * R + WIN - 1) / WIN;        // wave-uniform; short last bands only drop stores
+    for (int k = 0; k < niter; k++) {
+#pragma unroll
+        for (int m = 0; m < WIN; m++) {
+            const int j = k * WIN + m;
+            // DMAs/stores younger than row j's: prologue rows only count 2 each, steady state 3 per step
+            if (j < P) wait_vmcnt<2 * (P - 1)>(); else wait_vmcnt<3 * P - 2>();
+            // The row reads are inline asm: hipcc orders every ds_read it can see behind ALL in-flight LDS-DMA
+            // with s_waitcnt vmcnt(0), which would serialise the ring.  The statement returns with the data
+            // landed (its own lgkmcnt(0)); the counted vmcnt above is what orders it behind row j's DMA.
+            const unsigned soff = ring_off + (unsigned)(j % D) * (unsigned)ROWB;
+            u32x2 a, b;
+            u32x4 c;
+            asm volatile("ds_read_b64 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b64 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(a), "=&v"(c), "=&v"(b)
+                         : "v"(soff + (unsigned)ol), "v"(soff + (unsigned)oc), "v"(soff + (unsigned)orr)
+                         : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            uint32_t w[8];
+            w[0] = a.x; w[1] = a.y; w[2] = c.x; w[3] = c.y; w[4] = c.z; w[5] = c.w; w[6] = b.x; w[7] = b.y;
+            issue_row(j + P);                                // into the slot read two steps ago
+            hrow_window<C, R>(w, any_edge, at_start, at_end, hw[m]);
+            const int i = j - 2 * R;                         // output row completed by this input row
+            uint32_t o[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if constexpr (R == 1) {
+                    // rows i, i+1, i+2 sit in window slots m+1, m+2, m (mod 3)
+                    const uint32_t se = (((hw[(m + 2) % WIN][q] << 1) + hw[(m + 1) % WIN][q]) + hw[m][q]) << 4;
+                    const uint32_t so = (((hw[(m + 2) % WIN][4 + q] << 1) + hw[(m + 1) % WIN][4 + q]) + hw[m][4 + q]) << 4;
+                    o[q] = __builtin_amdgcn_perm(so, se, 0x07030501u);
+                } else {
+                    // rows i..i+4 sit in window slots m+1, m+2, m+3, m+4, m (mod 5)
+                    const uint32_t se = mad6(hw[(m + 3) % WIN][q],
+                                             ((hw[(m + 2) % WIN][q] + hw[(m + 4) % WIN][q]) << 2) +
+                                                 (hw[(m + 1) % WIN][q] + hw[m][q]));
+                    const uint32_t so = mad6(hw[(m + 3) % WIN][4 + q],
+                                             ((hw[(m + 2) % WIN][4 + q] + hw[(m + 4) % WIN][4 + q]) << 2) +
+                                                 (hw[(m + 1) % WIN][4 + q] + hw[m][4 + q]));
+                    o[q] = __builtin_amdgcn_perm(so, se, 0x07030501u);
+                }
+            }
+            u32x4 v; v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
+            const bool st = i >= 0 && i < rows_out;          // exactly one store per step, dropped when not wanted
+            __builtin_amdgcn_raw_buffer_store_b128(v, rout, (int)(st ? dst_off + (unsigned)i * (unsigned)p.pitch : OOB), 0, 0);
+        }
+    }
+    wait_vmcnt<0>();                                         // the last prefetches land before the LDS is released
 }
 
 // ----------------------------------------------------------------------------------
@@ -311,7 +497,7 @@ __global__ __launch_bounds__(256) void blur_generic_kernel(const GenericParams p
 Tunables &tunables()
 {
     static Tunables t = [] {
-        Tunables v{1, 0, 1};     // rpg 0 = choose per launch
+        Tunables v{1, 0, 1, 0, 0, 0, 0, 0};  // rpg 0 / stream_bh 0 = choose per launch
         if (const char *e = getenv("MI_BLUR_STAGE")) v.stage_dma = strcmp(e, "reg") != 0;
         if (const char *e = getenv("MI_BLUR_RPG")) { const int r = atoi(e); v.rpg = (r == 4 || r == 8 || r == 16) ? r : 0; }
         if (const char *e = getenv("MI_BLUR_XCD")) v.xcd_remap = atoi(e) != 0;
@@ -407,11 +593,52 @@ static int launch_tiled(const LaunchDesc &d)
     if (nblocks > 0x7fffffffLL) return MI_BLUR_ERR_INVALID;
     p.nblocks = (unsigned)nblocks;
     p.xcd = tun.xcd_remap && nblocks >= 16;
+    p.debug_copy = tun.debug_copy;
+    p.nt_load = tun.nt_load; p.nt_store = tun.nt_store;
 
     const dim3 grid((unsigned)nblocks), block((unsigned)((p.ncols * p.ngroups + 63) / 64 * 64));
     const size_t lds = (size_t)(p.TH + 2 * R) * (p.ncols + 2) * 16;
     return R == 1 ? launch_tiled_r<1>(d, p, grid, block, lds, rpg, tun.stage_dma != 0)
                   : launch_tiled_r<2>(d, p, grid, block, lds, rpg, tun.stage_dma != 0);
+}
+
+static int launch_stream(const LaunchDesc &d)
+{
+    const Tunables &tun = tunables();
+    const int pitch = d.width * d.channels, cpr = pitch / 16, rows = d.y1 - d.y0;
+    StreamParams p{};
+    p.in = d.in; p.out = d.out;
+    p.in_stride = (long long)d.band_rows * pitch;
+    p.out_stride = (long long)rows * pitch;
+    p.pitch = pitch; p.cpr = cpr; p.H = d.band_rows; p.y0 = d.y0; p.y1 = d.y1;
+    // Band height: tall bands re-read fewer halo rows (2R/BH), short ones give small grids enough waves.
+    int BH = tun.stream_bh;
+    if (BH <= 0) {
+        BH = 64;
+        while (BH > 8 && (long long)d.n_images * ((rows + BH - 1) / BH) * cpr / 64 < 256 * 16) BH >>= 1;
+    }
+    if (BH > rows) BH = rows;
+    p.BH = BH;
+    p.nbands = (rows + BH - 1) / BH;
+    p.total = (long long)d.n_images * p.nbands * cpr;
+    p.total_images = d.n_images;
+    if (p.total >= 0x7fffffffLL) return MI_BLUR_ERR_INVALID;
+    const long long nblocks = (p.total + 255) / 256;
+    p.nblocks = (unsigned)nblocks;
+    p.xcd = tun.xcd_remap && nblocks >= 16;
+    const dim3 grid((unsigned)nblocks), block(256);
+    const size_t lds = 4 * STREAM_D * STREAM_ROWB;
+    switch (d.channels * 10 + d.radius) {
+    case 11: return do_launch(blur_stream_kernel<1, 1>, grid, block, lds, d, p);
+    case 12: return do_launch(blur_stream_kernel<1, 2>, grid, block, lds, d, p);
+    case 21: return do_launch(blur_stream_kernel<2, 1>, grid, block, lds, d, p);
+    case 22: return do_launch(blur_stream_kernel<2, 2>, grid, block, lds, d, p);
+    case 31: return do_launch(blur_stream_kernel<3, 1>, grid, block, lds, d, p);
+    case 32: return do_launch(blur_stream_kernel<3, 2>, grid, block, lds, d, p);
+    case 41: return do_launch(blur_stream_kernel<4, 1>, grid, block, lds, d, p);
+    case 42: return do_launch(blur_stream_kernel<4, 2>, grid, block, lds, d, p);
+    }
+    return MI_BLUR_ERR_INVALID;
 }
 
 static int launch_generic(const LaunchDesc &d)
@@ -441,9 +668,12 @@ int launch(const LaunchDesc &d)
     if (d.n_images == 0) return MI_BLUR_OK;
     const bool can_tile = tiled_eligible(d.in, d.out, d.width, d.channels);
     switch (d.variant) {
-    case MI_BLUR_VARIANT_AUTO: return can_tile ? launch_tiled(d) : launch_generic(d);
+    case MI_BLUR_VARIANT_AUTO:
+        if (!can_tile) return launch_generic(d);
+        return tunables().prefer_stream ? launch_stream(d) : launch_tiled(d);
     case MI_BLUR_VARIANT_GENERIC: return launch_generic(d);
     case MI_BLUR_VARIANT_TILED: return can_tile ? launch_tiled(d) : MI_BLUR_ERR_INVALID;
+    case MI_BLUR_VARIANT_STREAM: return can_tile ? launch_stream(d) : MI_BLUR_ERR_INVALID;
     }
     return MI_BLUR_ERR_INVALID;
 }

@@ -72,6 +72,11 @@ extern "C" int mi_blur_set_option(const char *key, int value)
     if (!strcmp(key, "stage_dma")) t.stage_dma = value != 0;
     else if (!strcmp(key, "rows_per_thread")) { if (value != 0 && value != 4 && value != 8 && value != 16) return MI_BLUR_ERR_INVALID; t.rpg = value; }
     else if (!strcmp(key, "xcd_remap")) t.xcd_remap = value != 0;
+    else if (!strcmp(key, "debug_copy")) t.debug_copy = value != 0;   // ablation only (output is NOT a blur)
+    else if (!strcmp(key, "nt_load")) t.nt_load = value != 0;
+    else if (!strcmp(key, "nt_store")) t.nt_store = value != 0;
+    else if (!strcmp(key, "prefer_stream")) t.prefer_stream = value != 0;
+    else if (!strcmp(key, "stream_band_rows")) { if (value < 0 || value > 4096) return MI_BLUR_ERR_INVALID; t.stream_bh = value; }
     else return MI_BLUR_ERR_INVALID;
     return MI_BLUR_OK;
 }

@@ -53,7 +53,8 @@ typedef enum mi_blur_status {
 typedef enum mi_blur_variant {
     MI_BLUR_VARIANT_AUTO = 0,        /* LDS-tiled vector kernel when pitch%16==0 && channels<=4, else generic */
     MI_BLUR_VARIANT_GENERIC = 1,     /* one output byte per thread, any shape */
-    MI_BLUR_VARIANT_TILED = 2        /* LDS halo tile + 16-B vector loads (fails with _INVALID if ineligible) */
+    MI_BLUR_VARIANT_TILED = 2,       /* LDS halo tile + 16-B vector loads (fails with _INVALID if ineligible) */
+    MI_BLUR_VARIANT_STREAM = 3       /* barrier-free register sliding window + DPP row pass (same eligibility) */
 } mi_blur_variant;
 
 const char *mi_blur_strerror(int status);

@@ -40,6 +40,7 @@ def gpu_blur(pkg, L, torch, host, radius, variant=0, y0=None, y1=None, opts=None
 
 
 def reset_opts(L):
+    L.mi_blur_set_option(b"stream_band_rows", 0)
     L.mi_blur_set_option(b"stage_dma", 1)
     L.mi_blur_set_option(b"rows_per_thread", 0)
     L.mi_blur_set_option(b"xcd_remap", 1)
@@ -92,6 +93,46 @@ def test_tiled_kernel_option_cross(pkg, L, O, torch_cuda, opts, radius):
             host = O.lcg_stream(2, h, w, c)
             got = gpu_blur(pkg, L, torch_cuda, host, radius, pkg.VARIANT_TILED, opts=opts)
             assert np.array_equal(got, want_batch(O, host, radius))
+    finally:
+        reset_opts(L)
+
+
+@pytest.mark.parametrize("h,w,c", TILED_SHAPES)
+@pytest.mark.parametrize("radius", [1, 2])
+def test_stream_kernel_bit_exact(pkg, L, O, torch_cuda, h, w, c, radius):
+    """Barrier-free streaming variant (register sliding window + DPP row pass)."""
+    n = 3
+    try:
+        for host in adversarial(O, h, w, c, n, h * 11 + w):
+            want = want_batch(O, host, radius)
+            for opts in ({"stream_band_rows": 0, "xcd_remap": 1}, {"stream_band_rows": 5, "xcd_remap": 0},
+                         {"stream_band_rows": 64, "xcd_remap": 1}):
+                got = gpu_blur(pkg, L, torch_cuda, host, radius, pkg.VARIANT_STREAM, opts=opts)
+                assert np.array_equal(got, want), f"{(got != want).sum()} bytes differ, opts={opts}"
+    finally:
+        reset_opts(L)
+
+
+def test_stream_kernel_bands_and_big(pkg, L, O, torch_cuda):
+    try:
+        img = O.lcg_image(240, 320, 3)
+        for radius in (1, 2):
+            whole = O.blur(img, radius)
+            for G in (2, 3):
+                parts = []
+                for g in range(G):
+                    b = pkg.band_of(240, radius, g, G)
+                    band = np.ascontiguousarray(img[b["row_begin"] - b["halo_top"]: b["row_end"] + b["halo_bottom"]])[None]
+                    parts.append(gpu_blur(pkg, L, torch_cuda, band, radius, pkg.VARIANT_STREAM, y0=b["halo_top"],
+                                          y1=b["halo_top"] + b["row_end"] - b["row_begin"])[0])
+                assert np.array_equal(np.concatenate(parts), whole)
+        for (h, w, c, n) in [(256, 256, 3, 70), (1080, 1920, 3, 2), (75, 4096, 4, 2)]:
+            host = O.lcg_stream(n, h, w, c)
+            for radius in (1, 2):
+                a = gpu_blur(pkg, L, torch_cuda, host, radius, pkg.VARIANT_STREAM)
+                b = gpu_blur(pkg, L, torch_cuda, host, radius, pkg.VARIANT_TILED)
+                assert np.array_equal(a, b)
+                assert np.array_equal(a[0], O.blur(np.ascontiguousarray(host[0]), radius))
     finally:
         reset_opts(L)
 
