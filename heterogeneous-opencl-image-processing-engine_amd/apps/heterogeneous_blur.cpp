@@ -207,40 +207,19 @@ int main(int argc, char **argv)
         printf("Saved example output: %s\n\n", opt.save.c_str());
     }
 
-    // ---------------- performance analysis (heterogeneous_blur.c:609-724)
-    double time_cpu_transfer_in = cpu.tm.h2d_ms, time_cpu_kernel = cpu.tm.kernel_ms, time_cpu_transfer_out = cpu.tm.d2h_ms;
-    double time_gpu_transfer_in = 0, time_gpu_kernel = 0, time_gpu_transfer_out = 0;
+    // ---------------- performance analysis (heterogeneous_blur.c:609-724): sections come from host_common.h
+    DeviceTimes tcpu, tgpu;
+    tcpu.add(cpu.tm);
     uint64_t gpu_bytes_alg = 0, gpu_launches = 0;
-    for (auto &d : gpus) {
-        time_gpu_transfer_in += d.tm.h2d_ms; time_gpu_kernel += d.tm.kernel_ms; time_gpu_transfer_out += d.tm.d2h_ms;
-        gpu_bytes_alg += d.tm.bytes_alg; gpu_launches += d.tm.launches;
-    }
+    for (auto &d : gpus) { tgpu.add(d.tm); gpu_bytes_alg += d.tm.bytes_alg; gpu_launches += d.tm.launches; }
 
-    printf("========== PERFORMANCE RESULTS ==========\n\n");
-    printf("BATCH SIZE : %d\n", BATCH_SIZE);
-    printf("1. OVERALL EXECUTION TIME\n");
-    printf("   Total wall-clock time: %.2f ms (%.2f seconds)\n", time_total_processing, time_total_processing / 1000.0);
-    printf("   Total images processed: %d\n\n", NUM_IMAGES);
-
-    double time_cpu_total = 0;
+    report_header(BATCH_SIZE, time_total_processing, NUM_IMAGES);
     if (total_images_cpu > 0) {
-        time_cpu_total = time_cpu_transfer_in + time_cpu_kernel + time_cpu_transfer_out;
-        printf("2. CPU DEVICE (processed %d images)\n", total_images_cpu);
-        printf("   Total CPU time:        %.2f ms\n", time_cpu_total);
-        printf("   - Transfer IN:         %.2f ms (%.1f%%)\n", time_cpu_transfer_in, (time_cpu_transfer_in / time_cpu_total) * 100);
-        printf("   - Kernel execution:    %.2f ms (%.1f%%)\n", time_cpu_kernel, (time_cpu_kernel / time_cpu_total) * 100);
-        printf("   - Transfer OUT:        %.2f ms (%.1f%%)\n", time_cpu_transfer_out, (time_cpu_transfer_out / time_cpu_total) * 100);
-        printf("   Average per image:     %.2f ms\n\n", time_cpu_total / total_images_cpu);
+        report_device(2, "CPU", ("processed " + std::to_string(total_images_cpu) + " images").c_str(), tcpu, total_images_cpu);
+        printf("\n");
     }
-    double time_gpu_total = 0;
     if (total_images_gpu > 0) {
-        time_gpu_total = time_gpu_transfer_in + time_gpu_kernel + time_gpu_transfer_out;
-        printf("3. GPU DEVICE (processed %d images)\n", total_images_gpu);
-        printf("   Total GPU time:        %.2f ms\n", time_gpu_total);
-        printf("   - Transfer IN:         %.2f ms (%.1f%%)\n", time_gpu_transfer_in, (time_gpu_transfer_in / time_gpu_total) * 100);
-        printf("   - Kernel execution:    %.2f ms (%.1f%%)\n", time_gpu_kernel, (time_gpu_kernel / time_gpu_total) * 100);
-        printf("   - Transfer OUT:        %.2f ms (%.1f%%)\n", time_gpu_transfer_out, (time_gpu_transfer_out / time_gpu_total) * 100);
-        printf("   Average per image:     %.3f ms\n", time_gpu_total / total_images_gpu);
+        report_device(3, "GPU", ("processed " + std::to_string(total_images_gpu) + " images").c_str(), tgpu, total_images_gpu);
         if (G > 1)
             for (int g = 0; g < G; g++)
                 printf("   - %s: %llu images, in %.2f / kernel %.2f / out %.2f ms\n", gpus[g].name.c_str(),
@@ -248,44 +227,15 @@ int main(int argc, char **argv)
         printf("\n");
     }
     printf("====================\n");
-
-    double imbalance = 0, speedup_factor = 0;
-    if (total_images_cpu > 0 && total_images_gpu > 0) {
-        printf("4. DEVICE COMPARISON\n");
-        speedup_factor = time_cpu_total / time_gpu_total;
-        if (speedup_factor > 1.0) printf("   GPU is %.2fx FASTER than CPU\n", speedup_factor);
-        else printf("   CPU is %.2fx FASTER than GPU\n", 1.0 / speedup_factor);
-        printf("   CPU/GPU time ratio: %.2f\n\n", speedup_factor);
-
-        printf("5. WORKLOAD BALANCE\n");
-        imbalance = fabs(time_cpu_total - time_gpu_total) / fmax(time_cpu_total, time_gpu_total) * 100.0;
-        printf("   Workload imbalance: %.1f%%\n", imbalance);
-        if (time_cpu_total > time_gpu_total) printf("   CPU is the BOTTLENECK (%.2f ms slower)\n\n", time_cpu_total - time_gpu_total);
-        else printf("   GPU is the BOTTLENECK (%.2f ms slower)\n\n", time_gpu_total - time_cpu_total);
-
-        printf("6. BOTTLENECK IDENTIFICATION\n");
-        printf("   CPU bottleneck: ");
-        if (time_cpu_transfer_in + time_cpu_transfer_out > time_cpu_kernel)
-            printf("COMMUNICATION (%.1f%% of time)\n", ((time_cpu_transfer_in + time_cpu_transfer_out) / time_cpu_total) * 100);
-        else printf("COMPUTATION (%.1f%% of time)\n", (time_cpu_kernel / time_cpu_total) * 100);
-        printf("   GPU bottleneck: ");
-        if (time_gpu_transfer_in + time_gpu_transfer_out > time_gpu_kernel)
-            printf("COMMUNICATION (%.1f%% of time)\n", ((time_gpu_transfer_in + time_gpu_transfer_out) / time_gpu_total) * 100);
-        else printf("COMPUTATION (%.1f%% of time)\n", (time_gpu_kernel / time_gpu_total) * 100);
-    }
+    const bool both_worked = total_images_cpu > 0 && total_images_gpu > 0;
+    Comparison cmp;
+    if (both_worked) cmp = report_comparison(tcpu, tgpu);
     printf("\n");
-
-    printf("7. THROUGHPUT\n");
-    const double throughput_mpixels = ((double)NUM_IMAGES * width * height) / (time_total_processing / 1000.0) / 1000000.0;
-    const double img_per_sec = NUM_IMAGES / (time_total_processing / 1000.0);
-    printf("   Overall throughput: %.2f Megapixels/sec\n", throughput_mpixels);
-    printf("   Images per second: %.2f\n\n", img_per_sec);
-    printf("=========================================\n\n");
+    const Throughput thr = report_throughput(NUM_IMAGES, width, height, time_total_processing);
 
     double optimal_gpu_ratio = 0;
-    if (total_images_cpu > 0 && total_images_gpu > 0) {
-        const double t_cpu_per_image = time_cpu_total / total_images_cpu;
-        const double t_gpu_per_image = time_gpu_total / total_images_gpu;
+    if (both_worked) {                                   // heterogeneous_blur.c:712-724
+        const double t_cpu_per_image = tcpu.total() / total_images_cpu, t_gpu_per_image = tgpu.total() / total_images_gpu;
         optimal_gpu_ratio = t_cpu_per_image / (t_cpu_per_image + t_gpu_per_image);
         printf("8. OPTIMAL RATIO RECOMMENDATION\n");
         printf("   Based on measured performance:\n");
@@ -295,43 +245,18 @@ int main(int argc, char **argv)
         printf("   Run with: ./heterogeneous_blur both %.3f\n\n", optimal_gpu_ratio);
     }
 
-    // ---------------- MI355X addendum: kernel-only rate against the HBM roofline
-    double hbm_gbps = 0, roofline_frac = 0;
-    if (total_images_gpu > 0 && time_gpu_kernel > 0) {
-        hbm_gbps = (double)gpu_bytes_alg / (time_gpu_kernel / 1000.0) / 1e9 * G;   // kernel_ms is summed over G concurrent GPUs
-        roofline_frac = hbm_gbps / (HBM_PEAK_GBS * G);
-        printf("9. MI355X KERNEL ROOFLINE (%d GPU%s)\n", G, G > 1 ? "s" : "");
-        printf("   Launches: %llu (one per batch per GPU), avg %.2f us\n", (unsigned long long)gpu_launches,
-               time_gpu_kernel * 1000.0 / gpu_launches);
-        printf("   Algorithmic bytes (2*W*H*C per image): %.2f MB\n", gpu_bytes_alg / 1e6);
-        printf("   Kernel-only rate: %.0f images/sec, %.1f GB/s = %.1f%% of %.0f GB/s HBM peak\n",
-               total_images_gpu / (time_gpu_kernel / 1000.0) * G, hbm_gbps, roofline_frac * 100, HBM_PEAK_GBS * G);
-        if (!opt.resident)
+    Roofline rf;
+    if (total_images_gpu > 0) {
+        rf = report_roofline(9, G, gpu_bytes_alg, gpu_launches, tgpu.kernel_ms, total_images_gpu);
+        if (!opt.resident && tgpu.in_ms > 0 && tgpu.out_ms > 0)
             printf("   Host link: %.1f GB/s in, %.1f GB/s out (sum over GPUs)\n",
-                   (double)total_images_gpu * image_size / (time_gpu_transfer_in / 1000.0) / 1e9 * G,
-                   (double)total_images_gpu * image_size / (time_gpu_transfer_out / 1000.0) / 1e9 * G);
+                   (double)total_images_gpu * image_size / (tgpu.in_ms / 1000.0) / 1e9 * G,
+                   (double)total_images_gpu * image_size / (tgpu.out_ms / 1000.0) / 1e9 * G);
         printf("\n");
     }
-
-    if (!opt.csv.empty()) {   // columns of data/approach2/approach2/per_run.csv + hbm_gbps, roofline_frac, n_gpus
-        FILE *f = fopen(opt.csv.c_str(), "a");
-        if (f) {
-            if (ftell(f) == 0)
-                fprintf(f, "batch_size_file,run,file,mode,gpu_ratio_cfg,cpu_ratio_cfg,images,batches,img_w,img_h,wg_w,wg_h,wall_ms,"
-                           "cpu_images,cpu_total_ms,cpu_in_ms,cpu_kernel_ms,cpu_out_ms,cpu_ms_per_img,gpu_images,gpu_total_ms,gpu_in_ms,"
-                           "gpu_kernel_ms,gpu_out_ms,gpu_ms_per_img,speedup_gpu_vs_cpu,imbalance_pct,bottleneck,bottleneck_delta_ms,"
-                           "mpix_per_sec,img_per_sec,recommended_gpu_ratio,batch_size_log,hbm_gbps,roofline_frac,n_gpus\n");
-            fprintf(f, "%d,1,,%d,%.3f,%.3f,%d,%d,%d,%d,16,16,%.2f,%d,%.2f,%.2f,%.2f,%.2f,%.4f,%d,%.2f,%.2f,%.2f,%.2f,%.4f,%.2f,%.1f,%s,%.2f,%.2f,%.2f,%.3f,%d,%.1f,%.4f,%d\n",
-                    BATCH_SIZE, mode, gpu_ratio, 1 - gpu_ratio, NUM_IMAGES, NUM_BATCHES, width, height, time_total_processing,
-                    total_images_cpu, time_cpu_total, time_cpu_transfer_in, time_cpu_kernel, time_cpu_transfer_out,
-                    total_images_cpu ? time_cpu_total / total_images_cpu : 0.0,
-                    total_images_gpu, time_gpu_total, time_gpu_transfer_in, time_gpu_kernel, time_gpu_transfer_out,
-                    total_images_gpu ? time_gpu_total / total_images_gpu : 0.0, speedup_factor, imbalance,
-                    time_cpu_total > time_gpu_total ? "CPU" : "GPU", fabs(time_cpu_total - time_gpu_total),
-                    throughput_mpixels, img_per_sec, optimal_gpu_ratio, BATCH_SIZE, hbm_gbps, roofline_frac, G);
-            fclose(f);
-        }
-    }
+    if (!opt.csv.empty())
+        append_csv(opt.csv, BATCH_SIZE, mode == 0 ? "both" : mode == 1 ? "cpu" : "gpu", gpu_ratio, NUM_IMAGES, NUM_BATCHES, width, height,
+                   time_total_processing, total_images_cpu, tcpu, total_images_gpu, tgpu, cmp, thr, optimal_gpu_ratio, rf, G);
 
     // ---------------- cleanup (heterogeneous_blur.c:727-747)
     for (int s = 0; s < nslots; s++) { mi_blur_host_free(batch_input[s]); mi_blur_host_free(batch_output[s]); }

@@ -193,4 +193,113 @@ inline int parse_flags(int argc, char **argv, Options &o)
 
 constexpr double HBM_PEAK_GBS = 8000.0;   // MI355X HBM3E spec; ~6290 GB/s measured copy ceiling
 
+// ------------------------------------------------------------------------------------------------
+// Report blocks.  Wording and number formats follow the reference report (heterogeneous_blur.c:609-724,
+// split_image_blur.c:615-721) because scripts parse these lines; the layout of the code does not.
+// ------------------------------------------------------------------------------------------------
+struct DeviceTimes {                       // the reference's three buckets per device (:411-412)
+    double in_ms = 0, kernel_ms = 0, out_ms = 0;
+    double total() const { return in_ms + kernel_ms + out_ms; }
+    void add(const mi_blur_timing &t) { in_ms += t.h2d_ms; kernel_ms += t.kernel_ms; out_ms += t.d2h_ms; }
+};
+
+inline void report_header(int batch_size, double wall_ms, int images)
+{
+    printf("========== PERFORMANCE RESULTS ==========\n\n");
+    printf("BATCH SIZE : %d\n", batch_size);
+    printf("1. OVERALL EXECUTION TIME\n");
+    printf("   Total wall-clock time: %.2f ms (%.2f seconds)\n", wall_ms, wall_ms / 1000.0);
+    printf("   Total images processed: %d\n\n", images);
+}
+
+// "2. CPU DEVICE (...)" / "3. GPU DEVICE (...)": `what` is the text inside the parentheses.
+inline void report_device(int section, const char *dev, const char *what, const DeviceTimes &t, long long per_image_over)
+{
+    static const char *const label[3] = {"Transfer IN:     ", "Kernel execution:", "Transfer OUT:    "};
+    const double part[3] = {t.in_ms, t.kernel_ms, t.out_ms};
+    printf("%d. %s DEVICE (%s)\n", section, dev, what);
+    printf("   Total %s time:        %.2f ms\n", dev, t.total());
+    for (int i = 0; i < 3; i++) printf("   - %s    %.2f ms (%.1f%%)\n", label[i], part[i], part[i] / t.total() * 100);
+    if (per_image_over > 0) printf("   Average per image:     %.3f ms\n", t.total() / per_image_over);
+}
+
+inline void report_bottleneck_line(const char *dev, const DeviceTimes &t)
+{
+    printf("   %s bottleneck: ", dev);
+    if (t.in_ms + t.out_ms > t.kernel_ms) printf("COMMUNICATION (%.1f%% of time)\n", (t.in_ms + t.out_ms) / t.total() * 100);
+    else printf("COMPUTATION (%.1f%% of time)\n", t.kernel_ms / t.total() * 100);
+}
+
+struct Comparison { double speedup = 0, imbalance = 0; };
+
+// Sections 4-6 (device comparison, workload balance, bottleneck identification).
+inline Comparison report_comparison(const DeviceTimes &cpu, const DeviceTimes &gpu)
+{
+    Comparison c;
+    const double tc = cpu.total(), tg = gpu.total();
+    printf("4. DEVICE COMPARISON\n");
+    c.speedup = tc / tg;
+    if (c.speedup > 1.0) printf("   GPU is %.2fx FASTER than CPU\n", c.speedup);
+    else printf("   CPU is %.2fx FASTER than GPU\n", 1.0 / c.speedup);
+    printf("   CPU/GPU time ratio: %.2f\n\n", c.speedup);
+    printf("5. WORKLOAD BALANCE\n");
+    c.imbalance = fabs(tc - tg) / fmax(tc, tg) * 100.0;
+    printf("   Workload imbalance: %.1f%%\n", c.imbalance);
+    printf("   %s is the BOTTLENECK (%.2f ms slower)\n\n", tc > tg ? "CPU" : "GPU", fabs(tc - tg));
+    printf("6. BOTTLENECK IDENTIFICATION\n");
+    report_bottleneck_line("CPU", cpu);
+    report_bottleneck_line("GPU", gpu);
+    return c;
+}
+
+struct Throughput { double mpix = 0, img_s = 0; };
+inline Throughput report_throughput(int images, int width, int height, double wall_ms)
+{
+    Throughput t;
+    t.mpix = ((double)images * width * height) / (wall_ms / 1000.0) / 1000000.0;
+    t.img_s = images / (wall_ms / 1000.0);
+    printf("7. THROUGHPUT\n");
+    printf("   Overall throughput: %.2f Megapixels/sec\n", t.mpix);
+    printf("   Images per second: %.2f\n\n", t.img_s);
+    printf("=========================================\n\n");
+    return t;
+}
+
+// MI355X addendum: kernel-only rate against the HBM roofline (kernel_ms is summed over G concurrent GPUs).
+struct Roofline { double gbps = 0, frac = 0; };
+inline Roofline report_roofline(int section, int G, uint64_t bytes_alg, uint64_t launches, double kernel_ms_sum, long long images)
+{
+    Roofline r;
+    if (kernel_ms_sum <= 0 || launches == 0) return r;
+    r.gbps = (double)bytes_alg / (kernel_ms_sum / 1000.0) / 1e9 * G;
+    r.frac = r.gbps / (HBM_PEAK_GBS * G);
+    printf("%d. MI355X KERNEL ROOFLINE (%d GPU%s)\n", section, G, G > 1 ? "s" : "");
+    printf("   Launches: %llu (one per batch per GPU), avg %.2f us\n", (unsigned long long)launches, kernel_ms_sum * 1000.0 / launches);
+    printf("   Algorithmic bytes (2*W*H*C per image): %.2f MB\n", bytes_alg / 1e6);
+    printf("   Kernel-only rate: %.0f images/sec, %.1f GB/s = %.1f%% of %.0f GB/s HBM peak\n",
+           images / (kernel_ms_sum / 1000.0) * G, r.gbps, r.frac * 100, HBM_PEAK_GBS * G);
+    return r;
+}
+
+// One row in the column order of the reference's data/approach2/approach2/per_run.csv (+ 3 MI355X columns).
+inline void append_csv(const std::string &path, int batch, const char *mode, float gpu_ratio, int images, int batches, int width,
+                       int height, double wall_ms, long long cpu_images, const DeviceTimes &cpu, long long gpu_images,
+                       const DeviceTimes &gpu, const Comparison &cmp, const Throughput &thr, double recommended, const Roofline &rf, int G)
+{
+    FILE *f = fopen(path.c_str(), "a");
+    if (!f) { printf("Warning: cannot append to %s\n", path.c_str()); return; }
+    if (ftell(f) == 0)
+        fprintf(f, "batch_size_file,run,file,mode,gpu_ratio_cfg,cpu_ratio_cfg,images,batches,img_w,img_h,wg_w,wg_h,wall_ms,"
+                   "cpu_images,cpu_total_ms,cpu_in_ms,cpu_kernel_ms,cpu_out_ms,cpu_ms_per_img,gpu_images,gpu_total_ms,gpu_in_ms,"
+                   "gpu_kernel_ms,gpu_out_ms,gpu_ms_per_img,speedup_gpu_vs_cpu,imbalance_pct,bottleneck,bottleneck_delta_ms,"
+                   "mpix_per_sec,img_per_sec,recommended_gpu_ratio,batch_size_log,hbm_gbps,roofline_frac,n_gpus\n");
+    const double tc = cpu.total(), tg = gpu.total();
+    fprintf(f, "%d,1,,%s,%.3f,%.3f,%d,%d,%d,%d,16,16,%.2f,%lld,%.2f,%.2f,%.2f,%.2f,%.4f,%lld,%.2f,%.2f,%.2f,%.2f,%.4f,%.2f,%.1f,%s,%.2f,%.2f,%.2f,%.3f,%d,%.1f,%.4f,%d\n",
+            batch, mode, gpu_ratio, 1 - gpu_ratio, images, batches, width, height, wall_ms,
+            cpu_images, tc, cpu.in_ms, cpu.kernel_ms, cpu.out_ms, cpu_images ? tc / cpu_images : 0.0,
+            gpu_images, tg, gpu.in_ms, gpu.kernel_ms, gpu.out_ms, gpu_images ? tg / gpu_images : 0.0,
+            cmp.speedup, cmp.imbalance, tc > tg ? "CPU" : "GPU", fabs(tc - tg), thr.mpix, thr.img_s, recommended, batch, rf.gbps, rf.frac, G);
+    fclose(f);
+}
+
 }  // namespace host

@@ -181,78 +181,34 @@ int main(int argc, char **argv)
         printf("Saved example output: %s\n\n", opt.save.c_str());
     }
 
-    // ---------------- performance analysis (split_image_blur.c:615-721)
-    const double time_cpu_transfer_in = cpu.tm.h2d_ms, time_cpu_kernel = cpu.tm.kernel_ms, time_cpu_transfer_out = cpu.tm.d2h_ms;
-    double time_gpu_transfer_in = 0, time_gpu_kernel = 0, time_gpu_transfer_out = 0;
+    // ---------------- performance analysis (split_image_blur.c:615-721): sections come from host_common.h
+    DeviceTimes tcpu, tgpu;
+    tcpu.add(cpu.tm);
     uint64_t gpu_bytes_alg = 0, gpu_launches = 0;
-    for (auto &p : gpus) {
-        time_gpu_transfer_in += p.tm.h2d_ms; time_gpu_kernel += p.tm.kernel_ms; time_gpu_transfer_out += p.tm.d2h_ms;
-        gpu_bytes_alg += p.tm.bytes_alg; gpu_launches += p.tm.launches;
-    }
+    for (auto &p : gpus) { tgpu.add(p.tm); gpu_bytes_alg += p.tm.bytes_alg; gpu_launches += p.tm.launches; }
     const int cpu_output_rows = geo.cpu_output_rows, gpu_output_rows = geo.gpu_output_rows;
-    printf("========== PERFORMANCE RESULTS ==========\n\n");
-    printf("BATCH SIZE : %d\n", BATCH_SIZE);
-    printf("1. OVERALL EXECUTION TIME\n");
-    printf("   Total wall-clock time: %.2f ms (%.2f seconds)\n", time_total_processing, time_total_processing / 1000.0);
-    printf("   Total images processed: %d\n\n", NUM_IMAGES);
 
-    const double time_cpu_total = time_cpu_transfer_in + time_cpu_kernel + time_cpu_transfer_out;
-    printf("2. CPU DEVICE (processed %d images - top %d rows each)\n", NUM_IMAGES, cpu_output_rows);
-    printf("   Total CPU time:        %.2f ms\n", time_cpu_total);
-    printf("   - Transfer IN:         %.2f ms (%.1f%%)\n", time_cpu_transfer_in, (time_cpu_transfer_in / time_cpu_total) * 100);
-    printf("   - Kernel execution:    %.2f ms (%.1f%%)\n", time_cpu_kernel, (time_cpu_kernel / time_cpu_total) * 100);
-    printf("   - Transfer OUT:        %.2f ms (%.1f%%)\n\n", time_cpu_transfer_out, (time_cpu_transfer_out / time_cpu_total) * 100);
-
-    const double time_gpu_total = time_gpu_transfer_in + time_gpu_kernel + time_gpu_transfer_out;
-    printf("3. GPU DEVICE (processed %d images - bottom %d rows each)\n", NUM_IMAGES, gpu_output_rows);
-    printf("   Total GPU time:        %.2f ms\n", time_gpu_total);
-    printf("   - Transfer IN:         %.2f ms (%.1f%%)\n", time_gpu_transfer_in, (time_gpu_transfer_in / time_gpu_total) * 100);
-    printf("   - Kernel execution:    %.2f ms (%.1f%%)\n", time_gpu_kernel, (time_gpu_kernel / time_gpu_total) * 100);
-    printf("   - Transfer OUT:        %.2f ms (%.1f%%)\n", time_gpu_transfer_out, (time_gpu_transfer_out / time_gpu_total) * 100);
+    report_header(BATCH_SIZE, time_total_processing, NUM_IMAGES);
+    report_device(2, "CPU", ("processed " + std::to_string(NUM_IMAGES) + " images - top " + std::to_string(cpu_output_rows) + " rows each").c_str(), tcpu, 0);
+    printf("\n");
+    report_device(3, "GPU", ("processed " + std::to_string(NUM_IMAGES) + " images - bottom " + std::to_string(gpu_output_rows) + " rows each").c_str(), tgpu, 0);
     if (G > 1)
         for (auto &p : gpus)
             printf("   - %s: rows %d-%d, in %.2f / kernel %.2f / out %.2f ms\n", p.name.c_str(), p.out_row0,
                    p.out_row0 + p.out_rows - 1, p.tm.h2d_ms, p.tm.kernel_ms, p.tm.d2h_ms);
     printf("\n============================\n");
-
-    printf("4. DEVICE COMPARISON\n");
-    const double speedup_factor = time_cpu_total / time_gpu_total;
-    if (speedup_factor > 1.0) printf("   GPU is %.2fx FASTER than CPU\n", speedup_factor);
-    else printf("   CPU is %.2fx FASTER than GPU\n", 1.0 / speedup_factor);
-    printf("   CPU/GPU time ratio: %.2f\n\n", speedup_factor);
-
-    printf("5. WORKLOAD BALANCE\n");
-    const double imbalance = fabs(time_cpu_total - time_gpu_total) / fmax(time_cpu_total, time_gpu_total) * 100.0;
-    printf("   Workload imbalance: %.1f%%\n", imbalance);
-    if (time_cpu_total > time_gpu_total) printf("   CPU is the BOTTLENECK (%.2f ms slower)\n\n", time_cpu_total - time_gpu_total);
-    else printf("   GPU is the BOTTLENECK (%.2f ms slower)\n\n", time_gpu_total - time_cpu_total);
-
-    printf("6. BOTTLENECK IDENTIFICATION\n");
-    printf("   CPU bottleneck: ");
-    if (time_cpu_transfer_in + time_cpu_transfer_out > time_cpu_kernel)
-        printf("COMMUNICATION (%.1f%% of time)\n", ((time_cpu_transfer_in + time_cpu_transfer_out) / time_cpu_total) * 100);
-    else printf("COMPUTATION (%.1f%% of time)\n", (time_cpu_kernel / time_cpu_total) * 100);
-    printf("   GPU bottleneck: ");
-    if (time_gpu_transfer_in + time_gpu_transfer_out > time_gpu_kernel)
-        printf("COMMUNICATION (%.1f%% of time)\n", ((time_gpu_transfer_in + time_gpu_transfer_out) / time_gpu_total) * 100);
-    else printf("COMPUTATION (%.1f%% of time)\n", (time_gpu_kernel / time_gpu_total) * 100);
+    const Comparison cmp = report_comparison(tcpu, tgpu);
     printf("\n");
+    const Throughput thr = report_throughput(NUM_IMAGES, width, height, time_total_processing);
 
-    printf("7. THROUGHPUT\n");
-    const double throughput_mpixels = ((double)NUM_IMAGES * width * height) / (time_total_processing / 1000.0) / 1000000.0;
-    const double img_per_sec = NUM_IMAGES / (time_total_processing / 1000.0);
-    printf("   Overall throughput: %.2f Megapixels/sec\n", throughput_mpixels);
-    printf("   Images per second: %.2f\n\n", img_per_sec);
-    printf("=========================================\n\n");
-
-    printf("8. SPLIT-IMAGE STATISTICS\n");
-    printf("   CPU time per image: %.3f ms (for %d rows)\n", time_cpu_total / NUM_IMAGES, cpu_output_rows);
-    printf("   GPU time per image: %.3f ms (for %d rows)\n", time_gpu_total / NUM_IMAGES, gpu_output_rows);
+    printf("8. SPLIT-IMAGE STATISTICS\n");                   // split_image_blur.c:703-709
+    printf("   CPU time per image: %.3f ms (for %d rows)\n", tcpu.total() / NUM_IMAGES, cpu_output_rows);
+    printf("   GPU time per image: %.3f ms (for %d rows)\n", tgpu.total() / NUM_IMAGES, gpu_output_rows);
     printf("   Combined time per image: %.3f ms\n", time_total_processing / NUM_IMAGES);
     printf("   Current GPU ratio: %.1f%%\n\n", gpu_ratio * 100);
 
-    const double cpu_time_per_row = time_cpu_total / ((double)NUM_IMAGES * cpu_output_rows);
-    const double gpu_time_per_row = time_gpu_total / ((double)NUM_IMAGES * gpu_output_rows);
+    const double cpu_time_per_row = tcpu.total() / ((double)NUM_IMAGES * cpu_output_rows);   // :711-720
+    const double gpu_time_per_row = tgpu.total() / ((double)NUM_IMAGES * gpu_output_rows);
     const double optimal_gpu_ratio = cpu_time_per_row / (cpu_time_per_row + gpu_time_per_row);
     printf("9. OPTIMAL RATIO RECOMMENDATION\n");
     printf("   CPU: %.5f ms/row\n", cpu_time_per_row);
@@ -260,33 +216,11 @@ int main(int argc, char **argv)
     printf("   Recommended GPU ratio: %.1f%%\n", optimal_gpu_ratio * 100);
     printf("   Run with: ./split_image_blur %.3f\n\n", optimal_gpu_ratio);
 
-    double hbm_gbps = 0, roofline_frac = 0;
-    if (time_gpu_kernel > 0) {
-        hbm_gbps = (double)gpu_bytes_alg / (time_gpu_kernel / 1000.0) / 1e9 * G;
-        roofline_frac = hbm_gbps / (HBM_PEAK_GBS * G);
-        printf("10. MI355X KERNEL ROOFLINE (%d GPU%s)\n", G, G > 1 ? "s" : "");
-        printf("   Launches: %llu, avg %.2f us; algorithmic bytes %.2f MB\n", (unsigned long long)gpu_launches,
-               time_gpu_kernel * 1000.0 / gpu_launches, gpu_bytes_alg / 1e6);
-        printf("   Kernel-only: %.1f GB/s = %.1f%% of %.0f GB/s HBM peak\n\n", hbm_gbps, roofline_frac * 100, HBM_PEAK_GBS * G);
-    }
-
-    if (!opt.csv.empty()) {
-        FILE *f = fopen(opt.csv.c_str(), "a");
-        if (f) {
-            if (ftell(f) == 0)
-                fprintf(f, "batch_size_file,run,file,mode,gpu_ratio_cfg,cpu_ratio_cfg,images,batches,img_w,img_h,wg_w,wg_h,wall_ms,"
-                           "cpu_images,cpu_total_ms,cpu_in_ms,cpu_kernel_ms,cpu_out_ms,cpu_ms_per_img,gpu_images,gpu_total_ms,gpu_in_ms,"
-                           "gpu_kernel_ms,gpu_out_ms,gpu_ms_per_img,speedup_gpu_vs_cpu,imbalance_pct,bottleneck,bottleneck_delta_ms,"
-                           "mpix_per_sec,img_per_sec,recommended_gpu_ratio,batch_size_log,hbm_gbps,roofline_frac,n_gpus\n");
-            fprintf(f, "%d,1,,split,%.3f,%.3f,%d,%d,%d,%d,16,16,%.2f,%d,%.2f,%.2f,%.2f,%.2f,%.4f,%d,%.2f,%.2f,%.2f,%.2f,%.4f,%.2f,%.1f,%s,%.2f,%.2f,%.2f,%.3f,%d,%.1f,%.4f,%d\n",
-                    BATCH_SIZE, gpu_ratio, 1 - gpu_ratio, NUM_IMAGES, NUM_BATCHES, width, height, time_total_processing,
-                    NUM_IMAGES, time_cpu_total, time_cpu_transfer_in, time_cpu_kernel, time_cpu_transfer_out, time_cpu_total / NUM_IMAGES,
-                    NUM_IMAGES, time_gpu_total, time_gpu_transfer_in, time_gpu_kernel, time_gpu_transfer_out, time_gpu_total / NUM_IMAGES,
-                    speedup_factor, imbalance, time_cpu_total > time_gpu_total ? "CPU" : "GPU", fabs(time_cpu_total - time_gpu_total),
-                    throughput_mpixels, img_per_sec, optimal_gpu_ratio, BATCH_SIZE, hbm_gbps, roofline_frac, G);
-            fclose(f);
-        }
-    }
+    const Roofline rf = report_roofline(10, G, gpu_bytes_alg, gpu_launches, tgpu.kernel_ms, NUM_IMAGES);
+    printf("\n");
+    if (!opt.csv.empty())
+        append_csv(opt.csv, BATCH_SIZE, "split", gpu_ratio, NUM_IMAGES, NUM_BATCHES, width, height, time_total_processing,
+                   NUM_IMAGES, tcpu, NUM_IMAGES, tgpu, cmp, thr, optimal_gpu_ratio, rf, G);
 
     for (int s = 0; s < nslots; s++) { mi_blur_host_free(batch_input[s]); mi_blur_host_free(batch_output[s]); }
     mi_blur_destroy(cpu.ctx);
