@@ -120,7 +120,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=35)
     ap.add_argument("--images", type=int, default=5000, help="images per GPU per step (a1)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("MI_BLUR_BENCH_STREAMS", "4")))
-    ap.add_argument("--time-every", type=int, default=16,
+    ap.add_argument("--time-every", type=int, default=32,
                     help="a1: every n-th launch of the timed region carries dispatch timestamp events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extra", action="store_true",

@@ -132,14 +132,34 @@ __device__ __forceinline__ uint32_t hsum(const uint32_t (&Ew)[8], const uint32_t
 template <int C, int R>
 __device__ __forceinline__ void hrow_window(uint32_t (&w)[8], bool any_edge, bool at_start, bool at_end, uint32_t (&h)[8]);
 
-template <int C, int R>
-__device__ __forceinline__ void hrow(const uint8_t *lp, bool any_edge, bool at_start, bool at_end, uint32_t (&h)[8])
+// SHFL = wavefront-shuffle row pass: the 8 bytes either side of the chunk come from the neighbouring lanes'
+// registers (v_mov_b32_dpp wave_shr:1 / wave_shl:1); only lanes whose neighbour chunk is not held by the
+// adjacent lane (first/last lane of the wave, first/last chunk column of the tile) read them from the LDS halo.
+// !SHFL: every lane reads its 8+16+8 bytes from LDS.  Measured (profiles/): the LDS form is not slower — the
+// two ds_read_b64 it saves cost no VALU slot, the four DPP moves it adds do — so it is the default.
+template <int C, int R, bool SHFL>
+__device__ __forceinline__ void hrow(const uint8_t *lp, bool any_edge, bool at_start, bool at_end, bool lds_left, bool lds_right,
+                                     uint32_t (&h)[8])
 {
     uint32_t w[8];
-    const uint2 a = *reinterpret_cast<const uint2 *>(lp - 8);
     const uint4 c = *reinterpret_cast<const uint4 *>(lp);
-    const uint2 b = *reinterpret_cast<const uint2 *>(lp + 16);
-    w[0] = a.x; w[1] = a.y; w[2] = c.x; w[3] = c.y; w[4] = c.z; w[5] = c.w; w[6] = b.x; w[7] = b.y;
+    w[2] = c.x; w[3] = c.y; w[4] = c.z; w[5] = c.w;
+    if constexpr (SHFL) {
+        uint2 a = make_uint2(0u, 0u), b = make_uint2(0u, 0u);
+        if (lds_left) a = *reinterpret_cast<const uint2 *>(lp - 8);
+        if (lds_right) b = *reinterpret_cast<const uint2 *>(lp + 16);
+        // lane i takes lane i-1's last two dwords / lane i+1's first two; the LDS value where it was read
+        const uint32_t l0 = __builtin_amdgcn_update_dpp(0u, c.z, 0x138, 0xf, 0xf, false);   // wave_shr:1
+        const uint32_t l1 = __builtin_amdgcn_update_dpp(0u, c.w, 0x138, 0xf, 0xf, false);
+        const uint32_t r0 = __builtin_amdgcn_update_dpp(0u, c.x, 0x130, 0xf, 0xf, false);   // wave_shl:1
+        const uint32_t r1 = __builtin_amdgcn_update_dpp(0u, c.y, 0x130, 0xf, 0xf, false);
+        w[0] = lds_left ? a.x : l0; w[1] = lds_left ? a.y : l1;
+        w[6] = lds_right ? b.x : r0; w[7] = lds_right ? b.y : r1;
+    } else {
+        const uint2 a = *reinterpret_cast<const uint2 *>(lp - 8);
+        const uint2 b = *reinterpret_cast<const uint2 *>(lp + 16);
+        w[0] = a.x; w[1] = a.y; w[6] = b.x; w[7] = b.y;
+    }
     hrow_window<C, R>(w, any_edge, at_start, at_end, h);
 }
 
@@ -173,13 +193,12 @@ struct TiledParams {
     unsigned nblocks;
     int xcd;
     int debug_copy;                   // ablation only: skip the arithmetic, store the staged centre chunk
-    int nt_load, nt_store;            // non-temporal cache policy on the staging loads / the output stores
 };
 
 // ----------------------------------------------------------------------------------
 // LDS-tiled vector kernel
 // ----------------------------------------------------------------------------------
-template <int C, int R, int RPG, bool DMA>
+template <int C, int R, int RPG, bool DMA, bool SHFL = false>
 __global__ __launch_bounds__(256) void blur_tiled_kernel(const TiledParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -221,14 +240,9 @@ __global__ __launch_bounds__(256) void blur_tiled_kernel(const TiledParams p)
                 const uint8_t *g = img_in + ((unsigned)sr * (unsigned)p.pitch + col_off);
                 if constexpr (DMA) {
                     uint8_t *base = lds + (size_t)(u * rpi * cpr2) * 16u;    // wave-uniform; + lane*16 by HW
-                    if (p.nt_load)      // aux = 2: non-temporal (streamed-once) cache policy
-                        __builtin_amdgcn_global_load_lds(
-                            (const void __attribute__((address_space(1))) *)g,
-                            (void __attribute__((address_space(3))) *)base, 16, 0, 2);
-                    else
-                        __builtin_amdgcn_global_load_lds(
-                            (const void __attribute__((address_space(1))) *)g,
-                            (void __attribute__((address_space(3))) *)base, 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(
+                        (const void __attribute__((address_space(1))) *)g,
+                        (void __attribute__((address_space(3))) *)base, 16, 0, 0);   // default cache policy: nt (aux 2) measured 0-5 % slower
                 } else {
                     *reinterpret_cast<uint4 *>(lds + (size_t)(u * rpi * cpr2 + lane) * 16u) =
                         *reinterpret_cast<const uint4 *>(g);
@@ -256,20 +270,21 @@ __global__ __launch_bounds__(256) void blur_tiled_kernel(const TiledParams p)
         for (int r = 0; r < RPG; r++)
             if (r0 + r < rows_out) {
                 const u32x4 v = *reinterpret_cast<const u32x4 *>(lp + (r + R) * lrow);
-                if (p.nt_store) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(op + (size_t)r * (size_t)p.pitch));
-                else *reinterpret_cast<u32x4 *>(op + (size_t)r * (size_t)p.pitch) = v;
+                *reinterpret_cast<u32x4 *>(op + (size_t)r * (size_t)p.pitch) = v;
             }
         return;
     }
 
     constexpr int WIN = 2 * R + 1;
     uint32_t hw[WIN][8];
+    // shuffle row pass: which lanes cannot get a neighbour's bytes from the adjacent lane
+    const bool lds_left = (t & 63) == 0 || col == 0, lds_right = (t & 63) == 63 || col == nc - 1;
 #pragma unroll
-    for (int k = 0; k < 2 * R; k++) hrow<C, R>(lp + k * lrow, any_edge, at_start, at_end, hw[k]);
+    for (int k = 0; k < 2 * R; k++) hrow<C, R, SHFL>(lp + k * lrow, any_edge, at_start, at_end, lds_left, lds_right, hw[k]);
 
 #pragma unroll
     for (int r = 0; r < RPG; r++) {
-        hrow<C, R>(lp + (r + 2 * R) * lrow, any_edge, at_start, at_end, hw[(r + 2 * R) % WIN]);
+        hrow<C, R, SHFL>(lp + (r + 2 * R) * lrow, any_edge, at_start, at_end, lds_left, lds_right, hw[(r + 2 * R) % WIN]);
         uint32_t o[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -293,8 +308,7 @@ __global__ __launch_bounds__(256) void blur_tiled_kernel(const TiledParams p)
         }
         if (r0 + r < rows_out) {
             u32x4 v; v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
-            if (p.nt_store) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(op + (size_t)r * (size_t)p.pitch));
-            else *reinterpret_cast<u32x4 *>(op + (size_t)r * (size_t)p.pitch) = v;
+            *reinterpret_cast<u32x4 *>(op + (size_t)r * (size_t)p.pitch) = v;
         }
     }
 }
@@ -497,7 +511,7 @@ __global__ __launch_bounds__(256) void blur_generic_kernel(const GenericParams p
 Tunables &tunables()
 {
     static Tunables t = [] {
-        Tunables v{1, 0, 1, 0, 0, 0, 0, 0};  // rpg 0 / stream_bh 0 = choose per launch
+        Tunables v{1, 0, 1, 0, 0, 0, 0};  // rpg 0 / stream_bh 0 = choose per launch
         if (const char *e = getenv("MI_BLUR_STAGE")) v.stage_dma = strcmp(e, "reg") != 0;
         if (const char *e = getenv("MI_BLUR_RPG")) { const int r = atoi(e); v.rpg = (r == 4 || r == 8 || r == 16) ? r : 0; }
         if (const char *e = getenv("MI_BLUR_XCD")) v.xcd_remap = atoi(e) != 0;
@@ -529,6 +543,11 @@ template <int C, int R>
 static int launch_tiled_cr(const LaunchDesc &d, const TiledParams &p, dim3 grid, dim3 block, size_t lds,
                            int rpg, bool dma)
 {
+    if (tunables().row_shuffle && dma) {
+        if (rpg == 16) return do_launch(blur_tiled_kernel<C, R, 16, true, true>, grid, block, lds, d, p);
+        if (rpg == 4) return do_launch(blur_tiled_kernel<C, R, 4, true, true>, grid, block, lds, d, p);
+        return do_launch(blur_tiled_kernel<C, R, 8, true, true>, grid, block, lds, d, p);
+    }
     if (rpg == 16)
         return dma ? do_launch(blur_tiled_kernel<C, R, 16, true>, grid, block, lds, d, p)
                    : do_launch(blur_tiled_kernel<C, R, 16, false>, grid, block, lds, d, p);
@@ -594,7 +613,6 @@ static int launch_tiled(const LaunchDesc &d)
     p.nblocks = (unsigned)nblocks;
     p.xcd = tun.xcd_remap && nblocks >= 16;
     p.debug_copy = tun.debug_copy;
-    p.nt_load = tun.nt_load; p.nt_store = tun.nt_store;
 
     const dim3 grid((unsigned)nblocks), block((unsigned)((p.ncols * p.ngroups + 63) / 64 * 64));
     const size_t lds = (size_t)(p.TH + 2 * R) * (p.ncols + 2) * 16;

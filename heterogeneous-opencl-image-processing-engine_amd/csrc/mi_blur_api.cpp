@@ -73,8 +73,7 @@ extern "C" int mi_blur_set_option(const char *key, int value)
     else if (!strcmp(key, "rows_per_thread")) { if (value != 0 && value != 4 && value != 8 && value != 16) return MI_BLUR_ERR_INVALID; t.rpg = value; }
     else if (!strcmp(key, "xcd_remap")) t.xcd_remap = value != 0;
     else if (!strcmp(key, "debug_copy")) t.debug_copy = value != 0;   // ablation only (output is NOT a blur)
-    else if (!strcmp(key, "nt_load")) t.nt_load = value != 0;
-    else if (!strcmp(key, "nt_store")) t.nt_store = value != 0;
+    else if (!strcmp(key, "row_shuffle")) t.row_shuffle = value != 0;
     else if (!strcmp(key, "prefer_stream")) t.prefer_stream = value != 0;
     else if (!strcmp(key, "stream_band_rows")) { if (value < 0 || value > 4096) return MI_BLUR_ERR_INVALID; t.stream_bh = value; }
     else return MI_BLUR_ERR_INVALID;
@@ -622,10 +621,17 @@ Rccl &rccl()
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            r.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        // A process that already holds an RCCL (torch's bundled librccl.so has no soname and is registered under
+        // that name) must keep using that one: a second copy would sit on the same HIP runtime.
+        for (const char *name : {"librccl.so", "librccl.so.1"}) {
+            r.h = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
             if (r.h) break;
         }
+        if (!r.h)
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+                r.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (r.h) break;
+            }
         if (!r.h) return;
 #define MI_SYM(field, sym) r.field = (decltype(r.field))dlsym(r.h, #sym)
         MI_SYM(GetUniqueId, ncclGetUniqueId);

@@ -63,7 +63,10 @@ int mi_blur_version(void);
 /* Kernel tuning knobs (A/B benching and tests; defaults are the shipped configuration):
  *   "stage_dma"        1 = stage LDS tiles with global_load_lds (default), 0 = through VGPRs
  *   "rows_per_thread"  0 (default: chosen per launch from the grid size) | 4 | 8 | 16 output rows per thread
- *   "xcd_remap"        1 = XCD-contiguous blockIdx->tile map (default), 0 = identity */
+ *   "xcd_remap"        1 = XCD-contiguous blockIdx->tile map (default), 0 = identity
+ *   "row_shuffle"      1 = x-neighbour bytes by DPP wave shifts (LDS only at wave/tile edges), 0 = from LDS (default)
+ *   "prefer_stream"    1 = AUTO picks the streaming variant instead of the tiled one (default 0)
+ *   "stream_band_rows" streaming variant: output rows per wave (0 = chosen per launch) */
 int mi_blur_set_option(const char *key, int value);
 
 /* Number of visible HIP devices (0 is a valid answer: CPU-device contexts still work).

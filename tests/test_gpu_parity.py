@@ -40,6 +40,7 @@ def gpu_blur(pkg, L, torch, host, radius, variant=0, y0=None, y1=None, opts=None
 
 
 def reset_opts(L):
+    L.mi_blur_set_option(b"row_shuffle", 0)
     L.mi_blur_set_option(b"stream_band_rows", 0)
     L.mi_blur_set_option(b"stage_dma", 1)
     L.mi_blur_set_option(b"rows_per_thread", 0)
@@ -76,8 +77,9 @@ def test_tiled_kernel_bit_exact(pkg, L, O, torch_cuda, h, w, c, radius):
     try:
         for host in adversarial(O, h, w, c, n, h * 7 + w):
             want = want_batch(O, host, radius)
-            for opts in ({"stage_dma": 1, "rows_per_thread": 8, "xcd_remap": 1},
-                         {"stage_dma": 0, "rows_per_thread": 16, "xcd_remap": 0}):
+            for opts in ({"stage_dma": 1, "rows_per_thread": 8, "xcd_remap": 1, "row_shuffle": 0},
+                         {"stage_dma": 0, "rows_per_thread": 16, "xcd_remap": 0, "row_shuffle": 0},
+                         {"stage_dma": 1, "rows_per_thread": 0, "xcd_remap": 1, "row_shuffle": 1}):
                 got = gpu_blur(pkg, L, torch_cuda, host, radius, pkg.VARIANT_TILED, opts=opts)
                 assert np.array_equal(got, want), f"{(got != want).sum()} bytes differ, opts={opts}"
     finally:
@@ -308,3 +310,19 @@ def test_full_size_properties(pkg, L, O, torch_cuda):
     assert np.array_equal(got[-64:], O.blur(np.ascontiguousarray(img[-66:]), 2)[-64:])
     flat = gpu_blur(pkg, L, torch, np.full((1, 1080, 1920, 3), 255, np.uint8), 2)
     assert int(flat.min()) == 255
+
+
+def test_rccl_loads_and_single_rank_comm(pkg, L, torch_cuda):
+    """The RCCL leg cannot be exercised across GPUs on a one-GPU box; check what can be: the library resolves
+    RCCL lazily (sharing torch's copy when one is loaded), hands out a unique id, and a 1-rank communicator's
+    exchange is a no-op (both image edges clamp).  The exchange pattern itself: tests/test_multi_rank.py."""
+    raw = (C.c_uint8 * pkg.UNIQUE_ID_BYTES)()
+    pkg.check(L.mi_blur_comm_unique_id(raw), "mi_blur_comm_unique_id")
+    assert any(raw), "unique id is all zeros"
+    comm = C.c_void_p()
+    pkg.check(L.mi_blur_comm_init_rank(C.byref(comm), 1, 0, raw), "mi_blur_comm_init_rank")
+    band = torch_cuda.zeros(64 * 48 * 3, dtype=torch_cuda.uint8, device="cuda")
+    pkg.check(L.mi_blur_halo_exchange(comm, band.data_ptr(), 48, 3, 64, 1, None), "mi_blur_halo_exchange")
+    assert L.mi_blur_halo_exchange(comm, band.data_ptr(), 48, 3, 0, 1, None) == pkg.ERR_INVALID   # owned < radius
+    L.mi_blur_comm_destroy(comm)
+    assert L.mi_blur_comm_init_rank(C.byref(comm), 2, 5, raw) == pkg.ERR_INVALID
