@@ -139,11 +139,25 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # Rehearsal hooks (tests only): run the N>1 control path on a one-GPU box — every rank on the same device,
+    # gloo instead of RCCL for the barrier / max-over-ranks (RCCL refuses two ranks on one device).
+    backend = os.environ.get("MI_BLUR_BENCH_BACKEND", "nccl")
+    if "MI_BLUR_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["MI_BLUR_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    def dist_barrier():
+        if backend == "nccl":
+            dist.barrier(device_ids=[local_rank])
+        else:
+            dist.barrier()
 
     pkg = entry.load_package()
     L = pkg.lib()
@@ -151,7 +165,7 @@ def main() -> None:
 
     def barrier_sync():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            dist_barrier()
         torch.cuda.synchronize()
 
     extra = {}
@@ -176,11 +190,11 @@ def main() -> None:
             ctx.resident_run(per_gpu, batch, timed=time_every)
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            dist_barrier()
             torch.cuda.synchronize()
         local = time.perf_counter() - t0
         tm = ctx.sync()
-        elapsed = aggregate_max(local, dist if world > 1 else None, dev)
+        elapsed = aggregate_max(local, dist if world > 1 else None, dev if backend == "nccl" else None)
         units = per_gpu * world * K
         value = units / elapsed
         scaling = "weak"
@@ -291,10 +305,10 @@ def main() -> None:
         ev1.record()
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            dist_barrier()
             torch.cuda.synchronize()
         local = time.perf_counter() - t0
-        elapsed = aggregate_max(local, dist if world > 1 else None, dev)
+        elapsed = aggregate_max(local, dist if world > 1 else None, dev if backend == "nccl" else None)
         L.mi_blur_comm_destroy(comm)
         units = K
         value = units / elapsed

@@ -133,3 +133,26 @@ def test_a2_split_host(apps, O, tmp_path):
     # resident row-shard mode on one GPU (no exchange partner: both image edges clamp)
     r = run([spl, "--resident", "--gpus", "1", "--size", "2048x1024", "--iters", "5"], tmp_path)
     assert r.returncode == 0 and "EQUALS the single-device blur" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal(pkg):
+    """bench.py's N>1 control path (rank env, sharding offsets, barrier, max over ranks, rank-0 JSON) on a one-GPU
+    box: two ranks share cuda:0 and use gloo for the barrier (RCCL refuses two ranks on one device)."""
+    import json
+    import socket
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MI_BLUR_BENCH_BACKEND="gloo", MI_BLUR_BENCH_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(pkg.ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--images", "700"]
+    r = subprocess.run(cmd, cwd=pkg.ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, printed by rank 0"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d
+    assert d["config"]["images_per_gpu_per_step"] == 700 and d["roofline"]["bound"] == "hbm"
