@@ -36,9 +36,18 @@ def test_product_does_not_link_the_oracle(pkg):
     assert "oracle" not in ldd and "ref_blur" not in ldd
     syms = subprocess.run(["nm", "-D", pkg.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle_" not in syms and "ref_gaussian" not in syms
-    for f in os.listdir(pkg.CSRC):
-        text = open(os.path.join(pkg.CSRC, f)).read()
-        assert "oracle/" not in text.replace("with oracle/", "") or "shares no code" in text
+    # no product source includes, imports or dlopens anything under oracle/
+    import re
+    for d in (pkg.CSRC, pkg.APPS):
+        for f in os.listdir(d):
+            if not f.endswith((".cpp", ".hip", ".h")):
+                continue
+            text = open(os.path.join(d, f)).read()
+            assert not re.search(r'#include\s+"[^"]*oracle', text), f
+            assert not re.search(r'dlopen\([^)]*oracle', text), f
+            assert "liboracle" not in text and "libref_blur" not in text, f
+    init = open(os.path.join(pkg.PKG_DIR, "__init__.py")).read()
+    assert "import oracle" not in init and "from oracle" not in init and "liboracle" not in init
 
 
 def test_strerror(L):
