@@ -48,7 +48,9 @@ int main(int argc, char **argv)
     } else {
         printf("Mode: HETEROGENEOUS (CPU + GPU) [default]\n");
     }
-    if (npos > 2) {
+    if (npos > 2 && !strcmp(argv[2], "auto")) {
+        opt.auto_ratio = true;                    // closes the loop the reference leaves to the user (section 8 of its report)
+    } else if (npos > 2) {
         gpu_ratio = atof(argv[2]);
         if (gpu_ratio < 0.0f || gpu_ratio > 1.0f) {
             printf("Warning: gpu_ratio must be between 0.0 and 1.0. Using 0.5\n");
@@ -67,7 +69,8 @@ int main(int argc, char **argv)
     if (!opt.image.empty()) input_filename = opt.image.c_str();
     if (opt.resident && mode != 2) { printf("Error: --resident needs mode gpu\n"); return -1; }
 
-    if (mode == 0) printf("GPU ratio: %.1f%% GPU, %.1f%% CPU\n", gpu_ratio * 100, (1 - gpu_ratio) * 100);
+    if (mode == 0 && opt.auto_ratio) printf("GPU ratio: auto (first batch split 50/50, then the measured optimum)\n");
+    else if (mode == 0) printf("GPU ratio: %.1f%% GPU, %.1f%% CPU\n", gpu_ratio * 100, (1 - gpu_ratio) * 100);
     printf("========== HETEROGENEOUS CONFIGURATION ==========\n");
     printf("Input file: %s\n", opt.synthetic ? "(synthetic)" : input_filename);
     printf("Number of images in stream: %d\n", NUM_IMAGES);
@@ -193,6 +196,20 @@ int main(int argc, char **argv)
                 gpus[g].submitted[batch] = 1;
             }
             if (opt.verbose) printf("  Batch %d submitted.\n\n", batch + 1);
+
+            // "auto": measure the first batch and apply the reference's own recommendation
+            // (optimal = t_cpu_per_image / (t_cpu_per_image + t_gpu_per_image), heterogeneous_blur.c:713-715)
+            if (opt.auto_ratio && mode == 0 && batch == 0 && num_images_cpu > 0 && num_images_gpu > 0) {
+                mi_check(mi_blur_sync(cpu.ctx, &cpu.tm), "CPU sync failed");
+                DeviceTimes tc, tg;
+                tc.add(cpu.tm);
+                for (auto &d : gpus) { mi_check(mi_blur_sync(d.ctx, &d.tm), "GPU sync failed"); tg.add(d.tm); d.submitted[0] = 0; }
+                cpu.submitted[0] = 0;
+                const double t_cpu = tc.total() / num_images_cpu, t_gpu = tg.total() / G / num_images_gpu;
+                gpu_ratio = (float)(t_cpu / (t_cpu + t_gpu));
+                printf("Auto-calibrated GPU ratio: %.1f%% (CPU %.4f ms/image, GPU %.4f ms/image on the first batch)\n\n",
+                       gpu_ratio * 100, t_cpu, t_gpu);
+            }
         }
         // clFinish on every queue (heterogeneous_blur.c:538-539)
         if (cpu.ctx) mi_check(mi_blur_sync(cpu.ctx, &cpu.tm), "CPU sync failed");

@@ -158,6 +158,8 @@ struct Options {
     std::string csv;                     // --csv FILE   append one per_run.csv-style row
     std::string save;                    // --save FILE  write the first output image
     int iters = 100;                     // --iters N    (split_image_blur --resident)
+    bool iterate = false;                // --iterate    (split_image_blur --resident): blur the previous iteration's output
+    bool auto_ratio = false;             // gpu_ratio given as "auto": calibrate on the first batches (heterogeneous_blur both)
     bool size_given = false;
 };
 
@@ -186,6 +188,7 @@ inline int parse_flags(int argc, char **argv, Options &o)
         else if (a == "--csv") o.csv = next("--csv");
         else if (a == "--save") o.save = next("--save");
         else if (a == "--iters") o.iters = atoi(next("--iters"));
+        else if (a == "--iterate") o.iterate = true;
         else { printf("Error: unknown option %s\n", a.c_str()); exit(-1); }
     }
     return npos;

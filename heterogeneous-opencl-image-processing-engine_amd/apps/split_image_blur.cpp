@@ -2,7 +2,7 @@
 //
 //   split_image_blur [gpu_ratio] [batch]  [--image F | --synthetic | --size WxH] [--channels C] [--ksize 3|5]
 //                    [--images N] [--gpus G] [--slots S] [--threads T] [--verbose] [--csv FILE] [--save FILE]
-//   split_image_blur --resident [--gpus G] [--size WxH] [--ksize 3|5] [--iters N]
+//   split_image_blur --resident [--gpus G] [--size WxH] [--ksize 3|5] [--iters N] [--iterate] [--save FILE]
 //
 // Default mode keeps the reference host's semantics (split_image_blur.c:62-102 CLI, :142-173
 // geometry, :441-607 batch loop, :615-721 report): every image is split at
@@ -273,39 +273,65 @@ static int run_resident(const Options &opt)
     std::vector<mi_blur_comm *> comm(G, nullptr);
     mi_check(mi_blur_comm_init_all(comm.data(), G, devs.data()), "RCCL communicator init failed");
 
+    // --iterate: k successive blurs of the resident image (output shard -> next input shard), the case where the
+    // halo exchange genuinely recurs.  Without it every iteration blurs the same input again.
+    std::vector<uint8_t *> d_band2(G, nullptr);
+    if (opt.iterate)
+        for (int g = 0; g < G; g++) {
+            HIP_OK(hipSetDevice(g));
+            const size_t rows = owned[g] + band[g].halo_top + band[g].halo_bottom;
+            HIP_OK(hipMalloc((void **)&d_band2[g], rows * pitch));
+            HIP_OK(hipMemset(d_band2[g], 0, rows * pitch));
+        }
+    auto upload = [&]() {
+        for (int g = 0; g < G; g++) {
+            HIP_OK(hipSetDevice(g));
+            HIP_OK(hipMemcpy(d_band[g] + (size_t)band[g].halo_top * pitch, image.data() + (size_t)band[g].row_begin * pitch,
+                             (size_t)owned[g] * pitch, hipMemcpyHostToDevice));
+        }
+    };
     auto step = [&]() {
         std::vector<void *> st(G);
         for (int g = 0; g < G; g++) st[g] = stream[g];
         mi_check(mi_blur_halo_exchange_all(comm.data(), G, d_band.data(), W, C, owned.data(), radius, st.data()), "halo exchange failed");
         for (int g = 0; g < G; g++) {
             HIP_OK(hipSetDevice(g));
-            mi_check(mi_blur_enqueue_band(d_band[g], d_out[g], W, owned[g] + band[g].halo_top + band[g].halo_bottom, C, radius,
+            uint8_t *dst = opt.iterate ? d_band2[g] + (size_t)band[g].halo_top * pitch : d_out[g];
+            mi_check(mi_blur_enqueue_band(d_band[g], dst, W, owned[g] + band[g].halo_top + band[g].halo_bottom, C, radius,
                                           band[g].halo_top, band[g].halo_top + owned[g], stream[g]), "band launch failed");
         }
+        if (opt.iterate) std::swap(d_band, d_band2);     // the blurred shard is the next iteration's input
     };
     auto sync_all = [&]() { for (int g = 0; g < G; g++) { HIP_OK(hipSetDevice(g)); HIP_OK(hipStreamSynchronize(stream[g])); } };
     step(); sync_all();                                  // warm-up (also first RCCL connection set-up)
+    if (opt.iterate) upload();                           // start the timed chain from the original image again
     const double t0 = get_time_ms();
     for (int i = 0; i < opt.iters; i++) step();
     sync_all();
     const double ms = get_time_ms() - t0;
 
-    // verify against the single-device blur of the whole image on GPU 0
+    // verify against the single-device result on GPU 0 (one blur, or `iters` successive blurs with --iterate)
     std::vector<uint8_t> got(pitch * H), want(pitch * H);
     for (int g = 0; g < G; g++) {
         HIP_OK(hipSetDevice(g));
-        HIP_OK(hipMemcpy(got.data() + (size_t)band[g].row_begin * pitch, d_out[g], (size_t)owned[g] * pitch, hipMemcpyDeviceToHost));
+        const uint8_t *src = opt.iterate ? d_band[g] + (size_t)band[g].halo_top * pitch : d_out[g];
+        HIP_OK(hipMemcpy(got.data() + (size_t)band[g].row_begin * pitch, src, (size_t)owned[g] * pitch, hipMemcpyDeviceToHost));
     }
     {
         HIP_OK(hipSetDevice(0));
         uint8_t *di, *dout;
         HIP_OK(hipMalloc((void **)&di, pitch * H)); HIP_OK(hipMalloc((void **)&dout, pitch * H));
         HIP_OK(hipMemcpy(di, image.data(), pitch * H, hipMemcpyHostToDevice));
-        mi_check(mi_blur_enqueue(di, dout, W, H, C, radius, 1, nullptr), "whole-image launch failed");
+        const int passes = opt.iterate ? opt.iters : 1;
+        for (int i = 0; i < passes; i++) {
+            mi_check(mi_blur_enqueue(di, dout, W, H, C, radius, 1, nullptr), "whole-image launch failed");
+            std::swap(di, dout);
+        }
         HIP_OK(hipDeviceSynchronize());
-        HIP_OK(hipMemcpy(want.data(), dout, pitch * H, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(want.data(), di, pitch * H, hipMemcpyDeviceToHost));
         HIP_OK(hipFree(di)); HIP_OK(hipFree(dout));
     }
+    if (!opt.save.empty()) save_one_image(opt.save.c_str(), got.data(), W, H, C);
     const bool same = memcmp(got.data(), want.data(), pitch * H) == 0;
     printf("\nSharded result %s the single-device blur (fnv %016llx)\n", same ? "EQUALS" : "DIFFERS FROM",
            (unsigned long long)mi_blur_fnv1a64(got.data(), got.size()));
@@ -320,6 +346,7 @@ static int run_resident(const Options &opt)
         HIP_OK(hipSetDevice(g));
         mi_blur_comm_destroy(comm[g]);
         HIP_OK(hipFree(d_band[g])); HIP_OK(hipFree(d_out[g])); HIP_OK(hipStreamDestroy(stream[g]));
+        if (d_band2[g]) HIP_OK(hipFree(d_band2[g]));
     }
     return same ? 0 : 1;
 }

@@ -108,6 +108,9 @@ def test_a1_gpu_and_both_modes(apps, O, tmp_path):
               "6. BOTTLENECK IDENTIFICATION", "8. OPTIMAL RATIO RECOMMENDATION", "Run with: ./heterogeneous_blur both"]:
         assert s in r.stdout, s      # 500 images / 35: 14 x (10 cpu + 25 gpu) + last batch of 10 -> (3 cpu, 7 gpu)
     assert np.array_equal(read_ppm(tmp_path / "both.ppm"), want)
+    r = run([het, "both", "auto", "35", "--image", "in.ppm", "--images", "500", "--save", "auto.ppm"], tmp_path)
+    assert r.returncode == 0 and "Auto-calibrated GPU ratio:" in r.stdout, r.stdout + r.stderr
+    assert np.array_equal(read_ppm(tmp_path / "auto.ppm"), want)
     r = run([het, "gpu", "1.0", "35", "--size", "256x256", "--images", "5000", "--resident"], tmp_path)
     assert r.returncode == 0 and "9. MI355X KERNEL ROOFLINE" in r.stdout, r.stdout + r.stderr
 
@@ -133,6 +136,13 @@ def test_a2_split_host(apps, O, tmp_path):
     # resident row-shard mode on one GPU (no exchange partner: both image edges clamp)
     r = run([spl, "--resident", "--gpus", "1", "--size", "2048x1024", "--iters", "5"], tmp_path)
     assert r.returncode == 0 and "EQUALS the single-device blur" in r.stdout, r.stdout + r.stderr
+    # iterated blur (output shard feeds the next iteration): 3 successive 3x3 blurs == oracle applied 3 times
+    r = run([spl, "--resident", "--iterate", "--gpus", "1", "--size", "320x240", "--iters", "3", "--save", "it3.ppm"], tmp_path)
+    assert r.returncode == 0 and "EQUALS the single-device blur" in r.stdout, r.stdout + r.stderr
+    src = O.lcg_image(240, 320, 3)
+    for _ in range(3):
+        src = O.blur(src, 1)
+    assert np.array_equal(read_ppm(tmp_path / "it3.ppm"), src)
 
 
 @pytest.mark.gpu
