@@ -40,6 +40,7 @@ def gpu_blur(pkg, L, torch, host, radius, variant=0, y0=None, y1=None, opts=None
 
 
 def reset_opts(L):
+    L.mi_blur_set_option(b"prefer_stream", 0)
     L.mi_blur_set_option(b"row_shuffle", 0)
     L.mi_blur_set_option(b"stream_band_rows", 0)
     L.mi_blur_set_option(b"stage_dma", 1)
@@ -240,6 +241,37 @@ def test_context_submit_pageable_and_pinned(pkg, L, O, torch_cuda):
         assert np.array_equal(np.concatenate([top, bot]), want[0])
 
 
+def test_submit_bands_strided_batch(pkg, L, O, torch_cuda):
+    """Approach 2 for a whole batch (mi_blur_submit_bands): the same rows of every image of a contiguous batch
+    stream, gathered by one 2-D DMA (pinned memory) or through the pinned staging slot (pageable memory)."""
+    h, w, c, n, split = 96, 80, 3, 7, 31
+    host = O.lcg_stream(n, h, w, c)
+    want = O.blur_batch(host, 1)
+    pitch, isz = w * c, h * w * c
+    for pinned in (False, True):
+        for n_slots in (1, 3):
+            with pkg.Context(0, w, h, c, 1, max_batch=n, n_slots=n_slots) as ctx:
+                if pinned:
+                    p_in, p_out = L.mi_blur_host_alloc(host.nbytes), L.mi_blur_host_alloc(host.nbytes)
+                    C.memmove(p_in, host.ctypes.data, host.nbytes)
+                    C.memset(p_out, 0, host.nbytes)
+                else:
+                    out = np.zeros_like(host)
+                    p_in, p_out = host.ctypes.data, out.ctypes.data
+                # top band: rows [0, split) from input rows [0, split+1); bottom band: rows [split, h) from [split-1, h)
+                pkg.check(L.mi_blur_submit_bands(ctx.h, p_in, p_out, n, isz, split + 1, 0, 1), "submit_bands top")
+                pkg.check(L.mi_blur_submit_bands(ctx.h, p_in + (split - 1) * pitch, p_out + split * pitch, n, isz,
+                                                 h - split + 1, 1, 0), "submit_bands bottom")
+                tm = ctx.sync()
+                assert tm["launches"] == 2 and tm["images"] == 2 * n
+                if pinned:
+                    got = np.ctypeslib.as_array((C.c_uint8 * host.nbytes).from_address(p_out)).reshape(host.shape).copy()
+                    L.mi_blur_host_free(p_in); L.mi_blur_host_free(p_out)
+                else:
+                    got = out
+                assert np.array_equal(got, want), (pinned, n_slots)
+
+
 def test_resident_stream(pkg, L, O, torch_cuda):
     """Device-resident image stream: pool fill (synthetic LCG), batched passes, wrap-around."""
     h, w, c, pool = 64, 64, 3, 100
@@ -326,3 +358,36 @@ def test_rccl_loads_and_single_rank_comm(pkg, L, torch_cuda):
     assert L.mi_blur_halo_exchange(comm, band.data_ptr(), 48, 3, 0, 1, None) == pkg.ERR_INVALID   # owned < radius
     L.mi_blur_comm_destroy(comm)
     assert L.mi_blur_comm_init_rank(C.byref(comm), 2, 5, raw) == pkg.ERR_INVALID
+
+
+def test_randomised_sweep(pkg, L, O, torch_cuda):
+    """Seeded random sweep over shapes, channels, radius, batch, band row ranges, variants and tuning knobs:
+    every combination must reproduce the oracle byte for byte."""
+    rng = np.random.default_rng(20261004)
+    try:
+        for case in range(160):
+            c = int(rng.choice([1, 2, 3, 4, 5]))
+            radius = int(rng.choice([1, 2]))
+            if rng.random() < 0.75 and c <= 4:                     # tiled/stream eligible: pitch multiple of 16
+                w = int(rng.integers(1, 90)) * 16 // np.gcd(16, c)
+                variant = int(rng.choice([pkg.VARIANT_AUTO, pkg.VARIANT_TILED, pkg.VARIANT_STREAM]))
+            else:
+                w = int(rng.integers(1, 200))
+                variant = int(rng.choice([pkg.VARIANT_AUTO, pkg.VARIANT_GENERIC]))
+            assert variant in (pkg.VARIANT_AUTO, pkg.VARIANT_GENERIC) or (w * c) % 16 == 0
+            h = int(rng.integers(1, 150))
+            n = int(rng.integers(1, 6))
+            y0 = int(rng.integers(0, h))
+            y1 = int(rng.integers(y0 + 1, h + 1))
+            if rng.random() < 0.5:
+                y0, y1 = 0, h
+            opts = {"stage_dma": int(rng.integers(0, 2)), "rows_per_thread": int(rng.choice([0, 4, 8, 16])),
+                    "xcd_remap": int(rng.integers(0, 2)), "row_shuffle": int(rng.integers(0, 2)),
+                    "stream_band_rows": int(rng.choice([0, 3, 8, 40])), "prefer_stream": int(rng.integers(0, 2))}
+            host = rng.integers(0, 256, (n, h, w, c), dtype=np.uint8)
+            got = gpu_blur(pkg, L, torch_cuda, host, radius, variant, y0=y0, y1=y1, opts=opts)
+            want = want_batch(O, host, radius)[:, y0:y1]
+            assert np.array_equal(got, want), f"case {case}: shape {(n, h, w, c)} r{radius} rows [{y0},{y1}) variant {variant} {opts}"
+    finally:
+        reset_opts(L)
+        L.mi_blur_set_option(b"prefer_stream", 0)
