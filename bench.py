@@ -114,7 +114,7 @@ def cpu_baseline(n_target: int, h: int, w: int, c: int, radius: int) -> dict:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=["a1", "hd5", "a2"], default="a1")
     ap.add_argument("--batch", type=int, default=35)
@@ -176,7 +176,9 @@ def main() -> None:
         else:
             h, w, c, radius, per_gpu, batch, pool = 1080, 1920, 3, 2, 64, 64, 64
             name = "1920x1080x3, 5x5 blur, pool of 64 distinct resident images, one launch per pass"
-        ctx = pkg.Context(local_rank, w, h, c, radius, max_batch=1, n_slots=args.streams)   # resident runs use no staging
+        # host threads only generate the synthetic stream; keep ranks from oversubscribing the node between them
+        host_threads = max(2, min(32, len(os.sched_getaffinity(0)) // max(world, 1)))
+        ctx = pkg.Context(local_rank, w, h, c, radius, max_batch=1, n_slots=args.streams, n_threads=host_threads)   # resident runs use no staging
         ctx.resident_alloc(pool)
         ctx.resident_fill_synthetic(rank * per_gpu)
         for _ in range(W):
@@ -274,7 +276,7 @@ def main() -> None:
         out = torch.empty(owned * pitch, dtype=torch.uint8, device=dev)
         # synthetic content: rank g's owned rows = LCG image seeded by rank (content is irrelevant to timing)
         hostrows = np.empty((owned, Wd, c), np.uint8)
-        L.mi_blur_fill_synthetic(hostrows.ctypes.data, Wd, owned, c, rank, 1, 8)
+        L.mi_blur_fill_synthetic(hostrows.ctypes.data, Wd, owned, c, rank, 1, 1)
         band[b["halo_top"] * pitch:(b["halo_top"] + owned) * pitch] = torch.from_numpy(hostrows.reshape(-1)).to(dev)
         comm = C.c_void_p()
         idbuf = torch.zeros(pkg.UNIQUE_ID_BYTES, dtype=torch.uint8)
