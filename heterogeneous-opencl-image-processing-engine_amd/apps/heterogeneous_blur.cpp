@@ -94,7 +94,7 @@ int main(int argc, char **argv)
     // ---------------- device discovery (heterogeneous_blur.c:140-212)
     const int ngpu_visible = mi_blur_device_count();
     int G = mode == 1 ? 0 : opt.gpus;
-    if (mode != 1 && (ngpu_visible < 1 || G < 1 || G > ngpu_visible)) {
+    if (mode != 1 && !gpus_available(G)) {
         printf("Error: Could not find %d GPU device(s) (%d visible)\n", G < 1 ? 1 : G, ngpu_visible);
         return -1;
     }
@@ -110,9 +110,9 @@ int main(int argc, char **argv)
         cpu.submitted.assign(NUM_BATCHES, 0);
     }
     for (int g = 0; g < G; g++) {
-        mi_check(mi_blur_create(&gpus[g].ctx, g, width, height, channels, radius, BATCH_SIZE, nslots, 0),
+        mi_check(mi_blur_create(&gpus[g].ctx, hip_ordinal(g), width, height, channels, radius, BATCH_SIZE, nslots, 0),
                  "Failed to create GPU context");
-        gpus[g].name = "HIP device " + std::to_string(g);
+        gpus[g].name = "HIP device " + std::to_string(hip_ordinal(g)) + (virtual_gpus() ? " (logical GPU " + std::to_string(g) + ")" : "");
         printf("GPU device: %s\n", gpus[g].name.c_str());
         gpus[g].submitted.assign(NUM_BATCHES, 0);
     }

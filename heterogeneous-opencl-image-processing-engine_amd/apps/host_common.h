@@ -196,6 +196,13 @@ inline int parse_flags(int argc, char **argv, Options &o)
 
 constexpr double HBM_PEAK_GBS = 8000.0;   // MI355X HBM3E spec; ~6290 GB/s measured copy ceiling
 
+// Logical GPU g -> HIP ordinal.  Normally the identity (and G must not exceed the visible devices).  With
+// MI_BLUR_VIRTUAL_GPUS=1 (tests on a one-GPU box) G logical GPUs share the visible devices round-robin, each
+// with its own context and streams, so the sharding logic of the hosts runs unchanged.
+inline bool virtual_gpus() { const char *e = getenv("MI_BLUR_VIRTUAL_GPUS"); return e && atoi(e) != 0; }
+inline int hip_ordinal(int g) { const int n = mi_blur_device_count(); return virtual_gpus() && n > 0 ? g % n : g; }
+inline bool gpus_available(int G) { const int n = mi_blur_device_count(); return n >= 1 && G >= 1 && (G <= n || virtual_gpus()); }
+
 // ------------------------------------------------------------------------------------------------
 // Report blocks.  Wording and number formats follow the reference report (heterogeneous_blur.c:609-724,
 // split_image_blur.c:615-721) because scripts parse these lines; the layout of the code does not.

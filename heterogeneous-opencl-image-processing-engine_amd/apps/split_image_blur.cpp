@@ -101,7 +101,7 @@ int main(int argc, char **argv)
 
     // ---------------- devices (split_image_blur.c:175-247): the reference needs BOTH devices
     const int G = opt.gpus;
-    if (mi_blur_device_count() < 1 || G < 1 || G > mi_blur_device_count()) {
+    if (!gpus_available(G)) {
         printf("Error: Could not find both CPU and GPU devices (%d GPU(s) visible, %d asked)\n", mi_blur_device_count(), G);
         return -1;
     }
@@ -125,8 +125,8 @@ int main(int argc, char **argv)
         p.in_row0 = p.out_row0 - p.halo_top;
         p.band_rows = p.out_rows + p.halo_top + p.halo_bottom;
         if (p.out_rows <= 0) { printf("Error: more GPUs than GPU rows\n"); return -1; }
-        mi_check(mi_blur_create(&p.ctx, g, width, height, channels, HALO, BATCH_SIZE, nslots, 0), "Failed to create GPU context");
-        p.name = "HIP device " + std::to_string(g);
+        mi_check(mi_blur_create(&p.ctx, hip_ordinal(g), width, height, channels, HALO, BATCH_SIZE, nslots, 0), "Failed to create GPU context");
+        p.name = "HIP device " + std::to_string(hip_ordinal(g));
         printf("GPU device: %s (rows %d-%d)\n", p.name.c_str(), p.out_row0, p.out_row0 + p.out_rows - 1);
     }
     printf("\nKernel objects created\n\n");

@@ -166,3 +166,28 @@ def test_bench_two_rank_rehearsal(pkg):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d
     assert d["config"]["images_per_gpu_per_step"] == 700 and d["roofline"]["bound"] == "hbm"
+
+
+@pytest.mark.gpu
+def test_multi_gpu_sharding_on_virtual_gpus(apps, O, tmp_path):
+    """The hosts' --gpus G sharding (Approach 1: contiguous image shares per batch; Approach 2: GPU rows shared out
+    with their own halos) on G logical GPUs that share the one physical device (MI_BLUR_VIRTUAL_GPUS=1)."""
+    het, spl = apps
+    img = O.lcg_image(240, 320, 3)
+    write_ppm(tmp_path / "in.ppm", img)
+    env = dict(os.environ, MI_BLUR_VIRTUAL_GPUS="1")
+
+    def runv(cmd):
+        return subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
+
+    r = runv([het, "gpu", "1.0", "35", "--image", "in.ppm", "--images", "300", "--gpus", "4", "--save", "g4.ppm"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "3. GPU DEVICE (processed 300 images)" in r.stdout and r.stdout.count("logical GPU") >= 4
+    assert np.array_equal(read_ppm(tmp_path / "g4.ppm"), O.blur(img, 1))
+    r = runv([het, "both", "0.8", "35", "--image", "in.ppm", "--images", "300", "--gpus", "3", "--ksize", "5", "--save", "b3.ppm"])
+    assert r.returncode == 0 and np.array_equal(read_ppm(tmp_path / "b3.ppm"), O.blur(img, 2)), r.stdout + r.stderr
+    r = runv([spl, "0.837", "35", "--image", "in.ppm", "--images", "140", "--gpus", "3", "--save", "s3.ppm"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert np.array_equal(read_ppm(tmp_path / "s3.ppm"), O.blur(img, 1))
+    r = runv([spl, "0.5", "16", "--image", "in.ppm", "--images", "64", "--gpus", "2", "--ksize", "5", "--save", "s2.ppm"])
+    assert r.returncode == 0 and np.array_equal(read_ppm(tmp_path / "s2.ppm"), O.blur(img, 2)), r.stdout + r.stderr
