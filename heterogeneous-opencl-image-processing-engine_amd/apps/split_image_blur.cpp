@@ -242,12 +242,14 @@ static int run_resident(const Options &opt)
     const int G = opt.gpus, radius = opt.ksize == 3 ? 1 : 2;
     const int W = opt.size_given ? opt.syn_w : 8192, H = opt.size_given ? opt.syn_h : 8192, C = opt.syn_c;
     const size_t pitch = (size_t)W * C;
-    if (mi_blur_device_count() < G || G < 1) { printf("Error: %d GPU(s) asked, %d visible\n", G, mi_blur_device_count()); return -1; }
+    if (!gpus_available(G)) { printf("Error: %d GPU(s) asked, %d visible\n", G, mi_blur_device_count()); return -1; }
+    const bool p2p = opt.transport == "p2p" || virtual_gpus();      // RCCL refuses two ranks on one device
     if (H / G < radius) { printf("Error: shards of %d rows are thinner than the halo\n", H / G); return -1; }
     printf("========== SPLIT-IMAGE (RESIDENT, MULTI-GPU) ==========\n");
     printf("Image: %dx%d, %d channels (%.2f MB), %dx%d blur, %d GPU(s), %d iterations\n", W, H, C, pitch * H / 1e6, opt.ksize,
            opt.ksize, G, opt.iters);
-    printf("Halo: %d row(s) = %zu bytes per neighbour per direction, RCCL send/recv\n\n", radius, radius * pitch);
+    printf("Halo: %d row(s) = %zu bytes per neighbour per direction, %s\n\n", radius, radius * pitch,
+           p2p ? "hipMemcpyPeerAsync pushes" : "RCCL send/recv");
 
     std::vector<uint8_t> image(pitch * H);
     mi_blur_fill_synthetic(image.data(), W, H, C, 0, 1, 0);
@@ -256,11 +258,11 @@ static int run_resident(const Options &opt)
     std::vector<hipStream_t> stream(G);
     std::vector<int> owned(G), devs(G);
     for (int g = 0; g < G; g++) {
-        devs[g] = g;
+        devs[g] = hip_ordinal(g);
         mi_blur_band_of(H, radius, g, G, &band[g]);
         owned[g] = band[g].row_end - band[g].row_begin;
         const size_t rows = owned[g] + band[g].halo_top + band[g].halo_bottom;
-        HIP_OK(hipSetDevice(g));
+        HIP_OK(hipSetDevice(devs[g]));
         HIP_OK(hipStreamCreateWithFlags(&stream[g], hipStreamNonBlocking));
         HIP_OK(hipMalloc((void **)&d_band[g], rows * pitch));
         HIP_OK(hipMalloc((void **)&d_out[g], (size_t)owned[g] * pitch));
@@ -271,21 +273,22 @@ static int run_resident(const Options &opt)
         printf("GPU %d: rows %d-%d (+%d/+%d halo)\n", g, band[g].row_begin, band[g].row_end - 1, band[g].halo_top, band[g].halo_bottom);
     }
     std::vector<mi_blur_comm *> comm(G, nullptr);
-    mi_check(mi_blur_comm_init_all(comm.data(), G, devs.data()), "RCCL communicator init failed");
+    mi_check(p2p ? mi_blur_comm_init_p2p(comm.data(), G, devs.data()) : mi_blur_comm_init_all(comm.data(), G, devs.data()),
+             "communicator init failed");
 
     // --iterate: k successive blurs of the resident image (output shard -> next input shard), the case where the
     // halo exchange genuinely recurs.  Without it every iteration blurs the same input again.
     std::vector<uint8_t *> d_band2(G, nullptr);
     if (opt.iterate)
         for (int g = 0; g < G; g++) {
-            HIP_OK(hipSetDevice(g));
+            HIP_OK(hipSetDevice(devs[g]));
             const size_t rows = owned[g] + band[g].halo_top + band[g].halo_bottom;
             HIP_OK(hipMalloc((void **)&d_band2[g], rows * pitch));
             HIP_OK(hipMemset(d_band2[g], 0, rows * pitch));
         }
     auto upload = [&]() {
         for (int g = 0; g < G; g++) {
-            HIP_OK(hipSetDevice(g));
+            HIP_OK(hipSetDevice(devs[g]));
             HIP_OK(hipMemcpy(d_band[g] + (size_t)band[g].halo_top * pitch, image.data() + (size_t)band[g].row_begin * pitch,
                              (size_t)owned[g] * pitch, hipMemcpyHostToDevice));
         }
@@ -295,14 +298,14 @@ static int run_resident(const Options &opt)
         for (int g = 0; g < G; g++) st[g] = stream[g];
         mi_check(mi_blur_halo_exchange_all(comm.data(), G, d_band.data(), W, C, owned.data(), radius, st.data()), "halo exchange failed");
         for (int g = 0; g < G; g++) {
-            HIP_OK(hipSetDevice(g));
+            HIP_OK(hipSetDevice(devs[g]));
             uint8_t *dst = opt.iterate ? d_band2[g] + (size_t)band[g].halo_top * pitch : d_out[g];
             mi_check(mi_blur_enqueue_band(d_band[g], dst, W, owned[g] + band[g].halo_top + band[g].halo_bottom, C, radius,
                                           band[g].halo_top, band[g].halo_top + owned[g], stream[g]), "band launch failed");
         }
         if (opt.iterate) std::swap(d_band, d_band2);     // the blurred shard is the next iteration's input
     };
-    auto sync_all = [&]() { for (int g = 0; g < G; g++) { HIP_OK(hipSetDevice(g)); HIP_OK(hipStreamSynchronize(stream[g])); } };
+    auto sync_all = [&]() { for (int g = 0; g < G; g++) { HIP_OK(hipSetDevice(devs[g])); HIP_OK(hipStreamSynchronize(stream[g])); } };
     step(); sync_all();                                  // warm-up (also first RCCL connection set-up)
     if (opt.iterate) upload();                           // start the timed chain from the original image again
     const double t0 = get_time_ms();
@@ -313,7 +316,7 @@ static int run_resident(const Options &opt)
     // verify against the single-device result on GPU 0 (one blur, or `iters` successive blurs with --iterate)
     std::vector<uint8_t> got(pitch * H), want(pitch * H);
     for (int g = 0; g < G; g++) {
-        HIP_OK(hipSetDevice(g));
+        HIP_OK(hipSetDevice(devs[g]));
         const uint8_t *src = opt.iterate ? d_band[g] + (size_t)band[g].halo_top * pitch : d_out[g];
         HIP_OK(hipMemcpy(got.data() + (size_t)band[g].row_begin * pitch, src, (size_t)owned[g] * pitch, hipMemcpyDeviceToHost));
     }
@@ -343,7 +346,7 @@ static int run_resident(const Options &opt)
     printf("   Algorithmic bandwidth (incl. exchange + launch gaps): %.1f GB/s = %.1f%% of %d x %.0f GB/s\n", gbps,
            gbps / (HBM_PEAK_GBS * G) * 100, G, HBM_PEAK_GBS);
     for (int g = 0; g < G; g++) {
-        HIP_OK(hipSetDevice(g));
+        HIP_OK(hipSetDevice(devs[g]));
         mi_blur_comm_destroy(comm[g]);
         HIP_OK(hipFree(d_band[g])); HIP_OK(hipFree(d_out[g])); HIP_OK(hipStreamDestroy(stream[g]));
         if (d_band2[g]) HIP_OK(hipFree(d_band2[g]));

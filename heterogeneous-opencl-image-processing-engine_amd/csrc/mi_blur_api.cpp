@@ -656,6 +656,8 @@ inline int nccl_status(ncclResult_t e) { return e == ncclSuccess ? MI_BLUR_OK : 
 struct mi_blur_comm {
     ncclComm_t comm = nullptr;
     int n_ranks = 1, rank = 0, device = -1;
+    bool p2p = false;                            // single-process copy transport instead of RCCL
+    hipEvent_t ev_prev = nullptr, ev_push = nullptr;
 };
 
 static_assert(sizeof(ncclUniqueId) == MI_BLUR_UNIQUE_ID_BYTES, "ncclUniqueId size");
@@ -714,10 +716,44 @@ extern "C" int mi_blur_comm_init_all(mi_blur_comm **comms, int n_devices, const 
     return MI_BLUR_OK;
 }
 
+// Single-process communicator set whose halo rows move with hipMemcpyPeerAsync instead of RCCL: the
+// fallback when RCCL is unavailable, and what lets the row-shard flow run with several shards per device.
+extern "C" int mi_blur_comm_init_p2p(mi_blur_comm **comms, int n_devices, const int *devices)
+{
+    if (!comms || n_devices <= 0) return MI_BLUR_ERR_INVALID;
+    const int ndev = mi_blur_device_count();
+    if (ndev <= 0) return MI_BLUR_ERR_NO_DEVICE;
+    for (int i = 0; i < n_devices; i++) comms[i] = nullptr;
+    for (int i = 0; i < n_devices; i++) {
+        mi_blur_comm *c = new (std::nothrow) mi_blur_comm;
+        if (!c) return MI_BLUR_ERR_NOMEM;
+        c->n_ranks = n_devices; c->rank = i; c->device = devices ? devices[i] : i; c->p2p = true;
+        comms[i] = c;
+        if (c->device < 0 || c->device >= ndev) return MI_BLUR_ERR_NO_DEVICE;
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_prev, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_push, hipEventDisableTiming));
+    }
+    for (int i = 0; i + 1 < n_devices; i++) {     // neighbours on different devices: enable direct access both ways (best effort)
+        const int a = comms[i]->device, b = comms[i + 1]->device;
+        if (a == b) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) { (void)hipSetDevice(a); (void)hipDeviceEnablePeerAccess(b, 0); }
+        if (hipDeviceCanAccessPeer(&can, b, a) == hipSuccess && can) { (void)hipSetDevice(b); (void)hipDeviceEnablePeerAccess(a, 0); }
+        (void)hipGetLastError();
+    }
+    return MI_BLUR_OK;
+}
+
 extern "C" void mi_blur_comm_destroy(mi_blur_comm *c)
 {
     if (!c) return;
     if (c->comm) (void)rccl().CommDestroy(c->comm);
+    if (c->ev_prev || c->ev_push) {
+        (void)hipSetDevice(c->device);
+        if (c->ev_prev) (void)hipEventDestroy(c->ev_prev);
+        if (c->ev_push) (void)hipEventDestroy(c->ev_push);
+    }
     delete c;
 }
 
@@ -744,6 +780,7 @@ extern "C" int mi_blur_halo_exchange(mi_blur_comm *c, uint8_t *d_band, int width
 {
     if (!c || !d_band || width <= 0 || channels <= 0 || radius < 1 || owned_rows < radius) return MI_BLUR_ERR_INVALID;
     if (c->n_ranks == 1) return MI_BLUR_OK;            // nothing to exchange: both edges clamp
+    if (c->p2p) return MI_BLUR_ERR_STATE;              // the copy transport needs every rank: mi_blur_halo_exchange_all
     Rccl &r = rccl();
     if (!r.ok || !c->comm) return MI_BLUR_ERR_UNSUPPORTED;
     int rc = nccl_status(r.GroupStart());
@@ -760,12 +797,45 @@ extern "C" int mi_blur_halo_exchange_all(mi_blur_comm **comms, int n, uint8_t **
 {
     if (!comms || !d_bands || !owned_rows || n <= 0) return MI_BLUR_ERR_INVALID;
     if (n == 1) return MI_BLUR_OK;
+    for (int i = 0; i < n; i++) if (!comms[i] || owned_rows[i] < radius) return MI_BLUR_ERR_INVALID;
+    if (comms[0]->p2p) {
+        // Same rows, same offsets as the RCCL form; each rank PUSHES its edge rows into its neighbours' halo rows on
+        // its own stream.  Ordering by events: a push waits until the neighbour has finished whatever it queued
+        // before this call (its previous blur may still read those halo rows); a rank's later work waits for the
+        // pushes into its halos.
+        const size_t pitch = (size_t)width * channels, nbytes = pitch * (size_t)radius;
+        auto st = [&](int i) { return streams ? (hipStream_t)streams[i] : (hipStream_t) nullptr; };
+        auto top = [&](int i) { return i > 0 ? radius : 0; };
+        for (int i = 0; i < n; i++) {
+            HIP_TRY(hipSetDevice(comms[i]->device));
+            HIP_TRY(hipEventRecord(comms[i]->ev_prev, st(i)));
+        }
+        for (int i = 0; i < n; i++) {
+            HIP_TRY(hipSetDevice(comms[i]->device));
+            if (i > 0) {          // first owned rows -> bottom halo of rank i-1
+                HIP_TRY(hipStreamWaitEvent(st(i), comms[i - 1]->ev_prev, 0));
+                uint8_t *dst = d_bands[i - 1] + (size_t)(top(i - 1) + owned_rows[i - 1]) * pitch;
+                HIP_TRY(hipMemcpyPeerAsync(dst, comms[i - 1]->device, d_bands[i] + (size_t)top(i) * pitch, comms[i]->device, nbytes, st(i)));
+            }
+            if (i < n - 1) {      // last owned rows -> top halo of rank i+1
+                HIP_TRY(hipStreamWaitEvent(st(i), comms[i + 1]->ev_prev, 0));
+                const uint8_t *src = d_bands[i] + (size_t)(top(i) + owned_rows[i] - radius) * pitch;
+                HIP_TRY(hipMemcpyPeerAsync(d_bands[i + 1], comms[i + 1]->device, src, comms[i]->device, nbytes, st(i)));
+            }
+            HIP_TRY(hipEventRecord(comms[i]->ev_push, st(i)));
+        }
+        for (int i = 0; i < n; i++) {
+            HIP_TRY(hipSetDevice(comms[i]->device));
+            if (i > 0) HIP_TRY(hipStreamWaitEvent(st(i), comms[i - 1]->ev_push, 0));
+            if (i < n - 1) HIP_TRY(hipStreamWaitEvent(st(i), comms[i + 1]->ev_push, 0));
+        }
+        return MI_BLUR_OK;
+    }
     Rccl &r = rccl();
     if (!r.ok) return MI_BLUR_ERR_UNSUPPORTED;
     int rc = nccl_status(r.GroupStart());
     if (rc) return rc;
     for (int i = 0; i < n && !rc; i++) {
-        if (owned_rows[i] < radius) { rc = MI_BLUR_ERR_INVALID; break; }
         if (hipSetDevice(comms[i]->device) != hipSuccess) { (void)hipGetLastError(); rc = MI_BLUR_ERR_NO_DEVICE; break; }
         rc = halo_exchange_calls(r, comms[i], d_bands[i], (size_t)width * channels, owned_rows[i], radius,
                                  streams ? (hipStream_t)streams[i] : nullptr);

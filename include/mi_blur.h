@@ -234,6 +234,9 @@ typedef struct mi_blur_comm mi_blur_comm;
 int mi_blur_comm_unique_id(uint8_t id[MI_BLUR_UNIQUE_ID_BYTES]);
 int mi_blur_comm_init_rank(mi_blur_comm **comm, int n_ranks, int rank, const uint8_t id[MI_BLUR_UNIQUE_ID_BYTES]);
 int mi_blur_comm_init_all(mi_blur_comm **comms, int n_devices, const int *devices);
+/* Single-process set that moves halo rows with hipMemcpyPeerAsync instead of RCCL (fallback transport; also the
+ * only one that accepts several ranks on one device).  Use with mi_blur_halo_exchange_all. */
+int mi_blur_comm_init_p2p(mi_blur_comm **comms, int n_devices, const int *devices);
 void mi_blur_comm_destroy(mi_blur_comm *comm);
 
 /* d_band: this rank's shard laid out as [halo_top rows][owned rows][halo_bottom rows]

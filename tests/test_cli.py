@@ -191,3 +191,25 @@ def test_multi_gpu_sharding_on_virtual_gpus(apps, O, tmp_path):
     assert np.array_equal(read_ppm(tmp_path / "s3.ppm"), O.blur(img, 1))
     r = runv([spl, "0.5", "16", "--image", "in.ppm", "--images", "64", "--gpus", "2", "--ksize", "5", "--save", "s2.ppm"])
     assert r.returncode == 0 and np.array_equal(read_ppm(tmp_path / "s2.ppm"), O.blur(img, 2)), r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_resident_row_shards_on_virtual_gpus(apps, O, tmp_path):
+    """The resident row-shard flow of split_image_blur (BASELINE config 5 shape of work) with 4 shards on the one
+    physical GPU: halo rows travel between shards through the peer-copy transport (RCCL refuses two ranks on one
+    device), results must equal the single-device blur and the oracle, also when iterated (recurring exchange)."""
+    _, spl = apps
+    env = dict(os.environ, MI_BLUR_VIRTUAL_GPUS="1")
+    src = O.lcg_image(240, 320, 3)
+    for ksize, radius in (("3", 1), ("5", 2)):
+        r = subprocess.run([spl, "--resident", "--gpus", "4", "--size", "320x240", "--ksize", ksize, "--iters", "3", "--save", "one.ppm"],
+                           cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and "EQUALS the single-device blur" in r.stdout and "hipMemcpyPeerAsync" in r.stdout, r.stdout + r.stderr
+        assert np.array_equal(read_ppm(tmp_path / "one.ppm"), O.blur(src, radius))
+        r = subprocess.run([spl, "--resident", "--iterate", "--gpus", "4", "--size", "320x240", "--ksize", ksize, "--iters", "4", "--save", "it.ppm"],
+                           cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and "EQUALS the single-device blur" in r.stdout, r.stdout + r.stderr
+        want = src
+        for _ in range(4):
+            want = O.blur(want, radius)
+        assert np.array_equal(read_ppm(tmp_path / "it.ppm"), want)

@@ -391,3 +391,40 @@ def test_randomised_sweep(pkg, L, O, torch_cuda):
     finally:
         reset_opts(L)
         L.mi_blur_set_option(b"prefer_stream", 0)
+
+
+def test_p2p_halo_exchange_layout(pkg, L, O, torch_cuda):
+    """mi_blur_halo_exchange_all with the peer-copy transport on 3 shards of one device: after the exchange every
+    halo row holds the neighbour's edge row, owned rows are untouched, and blurring the bands reproduces the whole."""
+    torch = torch_cuda
+    H, W, Cn, R, G = 50, 32, 3, 2, 3
+    img = O.lcg_image(H, W, Cn)
+    pitch = W * Cn
+    bands, tens, owned = [], [], []
+    for g in range(G):
+        b = pkg.band_of(H, R, g, G)
+        rows = b["row_end"] - b["row_begin"] + b["halo_top"] + b["halo_bottom"]
+        t = torch.full((rows, W, Cn), 0xEE, dtype=torch.uint8, device="cuda")
+        t[b["halo_top"]:b["halo_top"] + b["row_end"] - b["row_begin"]] = torch.from_numpy(img[b["row_begin"]:b["row_end"]]).cuda()
+        bands.append(b); tens.append(t); owned.append(b["row_end"] - b["row_begin"])
+    comms = (C.c_void_p * G)()
+    devs = (C.c_int * G)(0, 0, 0)
+    pkg.check(L.mi_blur_comm_init_p2p(comms, G, devs), "comm_init_p2p")
+    ptrs = (C.c_void_p * G)(*[t.data_ptr() for t in tens])
+    own = (C.c_int * G)(*owned)
+    pkg.check(L.mi_blur_halo_exchange_all(comms, G, ptrs, W, Cn, own, R, None), "halo_exchange_all")
+    torch.cuda.synchronize()
+    outs = []
+    for g in range(G):
+        b = bands[g]
+        want_band = img[b["row_begin"] - b["halo_top"]: b["row_end"] + b["halo_bottom"]]
+        assert np.array_equal(tens[g].cpu().numpy(), want_band), f"shard {g} halo rows wrong"
+        out = torch.empty((owned[g], W, Cn), dtype=torch.uint8, device="cuda")
+        pkg.check(L.mi_blur_enqueue_band(tens[g].data_ptr(), out.data_ptr(), W, want_band.shape[0], Cn, R,
+                                         b["halo_top"], b["halo_top"] + owned[g], None))
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert np.array_equal(np.concatenate([o.cpu().numpy() for o in outs]), O.blur(img, R))
+    assert L.mi_blur_halo_exchange(comms[0], ptrs[0], W, Cn, owned[0], R, None) == pkg.ERR_STATE   # needs every rank
+    for g in range(G):
+        L.mi_blur_comm_destroy(comms[g])
