@@ -146,6 +146,7 @@ int main(int argc, char **argv)
     // ---------------- batch processing (split_image_blur.c:441-607)
     printf("Starting batch processing of %d images in %d batches...\n\n", NUM_IMAGES, NUM_BATCHES);
     std::vector<uint8_t> first_output;
+    Replicator replicate(opt.host_threads);
     const double time_start_total = get_time_ms();
     for (int batch = 0; batch < NUM_BATCHES; batch++) {
         if (opt.verbose) printf("=== Processing Batch %d/%d ===\n", batch + 1, NUM_BATCHES);
@@ -159,7 +160,7 @@ int main(int argc, char **argv)
             if (opt.save.size() && first_output.empty() && batch - nslots == 0)
                 first_output.assign(batch_output[s], batch_output[s] + image_size);
         }
-        for (int i = 0; i < batch_count; i++) memcpy(batch_input[s] + (size_t)i * image_size, original_image, image_size);
+        replicate.run(batch_input[s], original_image, image_size, batch_count);
         if (opt.verbose) printf("  Processing %d images (each split between CPU and GPU)\n", batch_count);
 
         // CPU: top rows of every image; GPU(s): bottom rows (split_image_blur.c:511-541), batched

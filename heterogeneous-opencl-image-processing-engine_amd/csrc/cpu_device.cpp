@@ -12,7 +12,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -23,6 +26,73 @@ int hardware_threads()
     unsigned n = std::thread::hardware_concurrency();
     return n ? (int)n : 1;
 }
+
+// Persistent worker pool: a batch of 10-35 small images is ~1 ms of work, less than spawning a thread per core.
+// Workers are created on first use (up to the hardware thread count) and reused by every parallel_for; callers
+// are serialised (one parallel_for at a time), which is what a single CPU device wants anyway.
+namespace {
+class Pool {
+public:
+    static Pool &get() { static Pool p; return p; }
+    // run fn(worker_index) on n_workers threads (including the caller); returns when all are done
+    void run(int n_workers, const std::function<void(int)> &fn)
+    {
+        if (n_workers <= 1) { fn(0); return; }
+        std::lock_guard<std::mutex> call(call_m_);
+        grow(n_workers - 1);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &fn; active_ = n_workers - 1; pending_ = n_workers - 1; gen_++;
+        }
+        cv_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+    ~Pool()
+    {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; gen_++; }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+
+private:
+    void grow(int n)
+    {
+        while ((int)th_.size() < n) {
+            const int id = (int)th_.size() + 1;
+            th_.emplace_back([this, id] { loop(id); });
+        }
+    }
+    void loop(int id)
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<void(int)> *fn = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                if (id <= active_) fn = fn_;
+            }
+            if (fn) {
+                (*fn)(id);
+                std::lock_guard<std::mutex> lk(m_);
+                if (--pending_ == 0) done_.notify_one();
+            }
+        }
+    }
+    std::mutex call_m_, m_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> th_;
+    const std::function<void(int)> *fn_ = nullptr;
+    unsigned long long gen_ = 0;
+    int active_ = 0, pending_ = 0;
+    bool stop_ = false;
+};
+}  // namespace
 
 // Rows [y_begin, y_end) of one image / band of H rows.
 void cpu_blur_rows(const uint8_t *in, uint8_t *out, int W, int H, int C, int R, int y_begin, int y_end,
@@ -83,12 +153,7 @@ void cpu_blur_batch(const uint8_t *in, uint8_t *out, int W, int band_rows, int C
         }
     };
     const int nt = (int)std::min<long long>(n_threads, items);
-    if (nt <= 1) { worker(); return; }
-    std::vector<std::thread> th;
-    th.reserve(nt - 1);
-    for (int i = 1; i < nt; i++) th.emplace_back(worker);
-    worker();
-    for (auto &t : th) t.join();
+    Pool::get().run(nt, [&](int) { worker(); });
 }
 
 // Synthetic stream: image i = LCG bytes, seed 0x9E3779B9 ^ i.
@@ -110,11 +175,7 @@ void fill_synthetic(uint8_t *host, int W, int H, int C, int first_index, int n_i
             }
         }
     };
-    const int nt = std::min(n_threads, n_images);
-    std::vector<std::thread> th;
-    for (int i = 1; i < nt; i++) th.emplace_back(worker);
-    worker();
-    for (auto &t : th) t.join();
+    Pool::get().run(std::min(n_threads, n_images), [&](int) { worker(); });
 }
 
 uint64_t fnv1a64(const uint8_t *p, size_t n)
