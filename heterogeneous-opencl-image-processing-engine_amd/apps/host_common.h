@@ -155,7 +155,8 @@ struct Options {
     int ksize = 3;                       // --ksize 3|5
     int images = 5000;                   // --images N   (NUM_IMAGES, heterogeneous_blur.c:44)
     int gpus = 1;                        // --gpus G
-    int slots = 3;                       // --slots S    staging slots / batch buffers in flight
+    int slots = 2;                       // --slots S    staging slots / batch buffers in flight (2 measured best:
+                                         // more concurrent H2D+D2H only contend on the host link)
     int threads = 0;                     // --threads T  CPU device threads (0 = all cores)
     int host_threads = 4;                // --host-threads T  helper threads that build each batch's stream
     bool verbose = false;                // --verbose    per-batch progress lines (heterogeneous_blur.c:420,463,599)
