@@ -105,7 +105,7 @@ int main(int argc, char **argv)
         mi_check(mi_blur_create(&cpu.ctx, MI_BLUR_DEVICE_CPU, width, height, channels, radius, BATCH_SIZE, nslots, opt.threads),
                  "Failed to create CPU context");
         const unsigned hc = std::thread::hardware_concurrency();
-        cpu.name = "host threads x" + std::to_string(opt.threads > 0 ? opt.threads : std::min((int)(hc ? hc : 1), 32));
+        cpu.name = "host threads x" + std::to_string(opt.threads > 0 ? opt.threads : std::min((int)(hc ? hc : 1), 16));
         printf("CPU device: %s\n", cpu.name.c_str());
         cpu.submitted.assign(NUM_BATCHES, 0);
     }

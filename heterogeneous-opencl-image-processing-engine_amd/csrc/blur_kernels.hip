@@ -231,7 +231,10 @@ __global__ __launch_bounds__(256) void blur_tiled_kernel(const TiledParams p)
         const int lane = t & 63, wv = t >> 6, nwaves = NT >> 6;
         const int rpi = 64 / cpr2;                    // >= 1
         const int lr = lane / cpr2, cc = lane - lr * cpr2;
-        const bool act = lr < rpi;
+        // halo chunks that fall outside the image row are never read (the x-clamp is synthesised from the edge
+        // chunk), so they are not loaded either: for full-row tiles that is both halo columns of every row
+        const bool dead_halo = (cc == 0 && x0c == 0) || (cc == cpr2 - 1 && x0c + nc == p.cpr);
+        const bool act = lr < rpi && !dead_halo;
         const unsigned col_off = (unsigned)min(max(x0c + cc - 1, 0), p.cpr - 1) * 16u;
         for (int u = wv; u * rpi < nrows; u += nwaves) {
             const int row = u * rpi + lr;

@@ -208,9 +208,9 @@ extern "C" int mi_blur_create(mi_blur_ctx **out_ctx, int device, int width, int 
     if (!c) return MI_BLUR_ERR_NOMEM;
     c->device = device; c->W = width; c->H = height; c->C = channels; c->R = radius;
     c->max_batch = max_batch;
-    // 0 = automatic: all cores up to 32.  Waking hundreds of workers for a ~1 ms batch costs more than it returns
-    // (measured on a 256-thread host: 8.5 k img/s with 256 workers vs. far more with 32); ask explicitly for more.
-    c->n_threads = n_threads > 0 ? n_threads : std::min(hardware_threads(), 32);
+    // 0 = automatic: all cores up to 16.  Waking hundreds of workers for a ~1 ms batch costs more than it returns
+    // (256-thread host, 256x256x3, batch 35: 8.5 k img/s with 256 workers, 235 k with 16, 190 k with 32); ask explicitly for more.
+    c->n_threads = n_threads > 0 ? n_threads : std::min(hardware_threads(), 16);
     c->image_bytes = (size_t)width * height * channels;
     if (device == MI_BLUR_DEVICE_CPU) { *out_ctx = c; return MI_BLUR_OK; }
 
