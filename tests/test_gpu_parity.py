@@ -428,3 +428,22 @@ def test_p2p_halo_exchange_layout(pkg, L, O, torch_cuda):
     assert L.mi_blur_halo_exchange(comms[0], ptrs[0], W, Cn, owned[0], R, None) == pkg.ERR_STATE   # needs every rank
     for g in range(G):
         L.mi_blur_comm_destroy(comms[g])
+
+
+def test_multi_stream_soak(pkg, L, O, torch_cuda):
+    """The bench's launch pattern under load: hundreds of batch-35 launches round-robin over 4 streams with sampled
+    timestamp events, repeated; afterwards randomly chosen pool images must still equal the oracle (no cross-stream
+    interference, no stale tile, no lost launch)."""
+    h, w, c, n = 256, 256, 3, 1500
+    rng = np.random.default_rng(5)
+    with pkg.Context(0, w, h, c, 1, max_batch=1, n_slots=4) as ctx:
+        ctx.resident_alloc(n)
+        ctx.resident_fill_synthetic(100)
+        for rep in range(40):
+            ctx.resident_run(n, 35, timed=7)
+        tm = ctx.sync()
+        assert tm["images"] == 40 * n and tm["launches"] == 40 * 43 and tm["kernel_ms"] > 0
+        got = np.zeros((1, h, w, c), np.uint8)
+        for idx in [0, 34, 35, n - 1] + [int(x) for x in rng.integers(0, n, 12)]:
+            ctx.resident_download(idx, got.ctypes.data, 1)
+            assert np.array_equal(got[0], O.blur(O.lcg_stream(1, h, w, c, first_index=100 + idx)[0], 1)), idx
