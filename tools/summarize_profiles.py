@@ -22,9 +22,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL = "blur_tiled_kernel"
 
 
+def newest(pattern):
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1] if files else None
+
+
 def rows(pattern):
-    files = glob.glob(pattern)
-    return list(csv.DictReader(open(files[0]))) if files else []
+    f = newest(pattern)      # gpurun merges new runs into the same directory: take the latest
+    return list(csv.DictReader(open(f))) if f else []
 
 
 def main():
@@ -49,7 +54,8 @@ def main():
         bench = json.loads(text[-1])
         shutil.copy(bj, os.path.join(dst, f"{tag}_{cfg}_bench.json"))
         stats = rows(os.path.join(src, f"trace_{cfg}", "*", "*_kernel_stats.csv"))
-        for f in glob.glob(os.path.join(src, f"trace_{cfg}", "*", "*_kernel_stats.csv")):
+        f = newest(os.path.join(src, f"trace_{cfg}", "*", "*_kernel_stats.csv"))
+        if f:
             shutil.copy(f, os.path.join(dst, f"{tag}_{cfg}_kernel_stats.csv"))
         srow = [r for r in stats if KERNEL in r["Name"]]
         srow.sort(key=lambda r: -float(r["TotalDurationNs"]))
