@@ -65,6 +65,22 @@ def test_golden_literals(O, golden):
     assert set(by["all255_4x4"]) == {255}
 
 
+def test_survey_leading_bytes(O):
+    """SURVEY §8c's table, from the surveyor's independent probe of the reference kernel: the first 8 output
+    bytes of each shape.  (Its hash column does not follow the FNV-1a-64 the text specifies — the 1x1 "identity"
+    row is not the FNV-1a-64 of bytes 66 233 63 — so the hashes in tests/golden/ were re-derived here from the
+    unmodified kernel, as the survey asks; the byte column is reproduced exactly.)"""
+    table = {(256, 256): [85, 199, 69, 123, 169, 111, 158, 105], (240, 320): [71, 190, 67, 106, 147, 76, 146, 87],
+             (1080, 1920): [111, 222, 56, 125, 189, 100, 150, 114], (16, 16): [93, 214, 96, 100, 183, 108, 125, 112],
+             (33, 17): [70, 217, 81, 92, 179, 107, 129, 103], (3, 5): [94, 217, 96, 125, 163, 110, 153, 97],
+             (1, 1): [66, 233, 63]}
+    for (h, w), first in table.items():
+        out = O.blur(O.lcg_image(h, w, 3), 1).reshape(-1)
+        assert out[:8].tolist() == first, (h, w)
+        if O.ref_available():
+            assert O.ref_blur(O.lcg_image(h, w, 3)).reshape(-1)[:8].tolist() == first
+
+
 def test_golden_a2_split(O, golden):
     """Approach-2 two-band procedure (split_image_blur.c:511-541) reproduces the reference's bytes."""
     for e in golden["a2_split"]:
