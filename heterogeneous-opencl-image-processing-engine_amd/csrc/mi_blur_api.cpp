@@ -29,6 +29,15 @@ using namespace mi_blur;
         if (e_ != hipSuccess) { (void)hipGetLastError(); return MI_BLUR_ERR_HIP_BASE - (int)e_; } \
     } while (0)
 
+// Runtime default, applied when the library is loaded and only if the user has not set it: keep kernel
+// arguments in host memory (HIP_FORCE_DEV_KERNARG=0).  With the runtime's gfx9 default (a device-memory
+// kernarg pool written over PCIe) a stream of argument-carrying launches issues at ~3.3 us per launch on this
+// platform, with host kernargs at ~1.6 us (tools/ubench/dispatch_floor.hip); the batch-35 stream is bounded by
+// that rate, not by the kernel (+30 % images/s measured).  The flag is read when the HIP
+// runtime initialises, so it takes effect if this library (or the Python package, which sets it too) is
+// loaded before the process's first HIP call.
+__attribute__((constructor)) static void mi_blur_runtime_defaults() { setenv("HIP_FORCE_DEV_KERNARG", "0", 0); }
+
 // ----------------------------------------------------------------------------------
 // status / discovery   (replaces cl_error strings + heterogeneous_blur.c:142-184)
 // ----------------------------------------------------------------------------------
