@@ -134,6 +134,7 @@ def lib() -> C.CDLL:
         "mi_blur_wait_oldest": (i, [vp]),
         "mi_blur_sync": (i, [vp, C.POINTER(Timing)]),
         "mi_blur_reset_timing": (None, [vp]),
+        "mi_blur_get_timing": (C.c_int, [vp, C.c_void_p]),
         "mi_blur_resident_alloc": (i, [vp, i]),
         "mi_blur_resident_fill_synthetic": (i, [vp, i]),
         "mi_blur_resident_upload": (i, [vp, i, u8p, i]),
@@ -232,6 +233,12 @@ class Context:
     def sync(self) -> dict:
         t = Timing()
         check(lib().mi_blur_sync(self.h, C.byref(t)), "mi_blur_sync")
+        return t.as_dict()
+
+    def timing(self) -> dict:
+        """Non-blocking snapshot of the buckets harvested so far."""
+        t = Timing()
+        check(lib().mi_blur_get_timing(self.h, C.byref(t)), "mi_blur_get_timing")
         return t.as_dict()
 
     def reset_timing(self) -> None:

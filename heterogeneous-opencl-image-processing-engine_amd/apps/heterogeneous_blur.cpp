@@ -170,6 +170,8 @@ int main(int argc, char **argv)
     int total_images_cpu = 0, total_images_gpu = 0;
     std::vector<uint8_t> first_output;
     Replicator replicate(opt.host_threads);
+    double last_harvest_ms = 0;
+    int rebalances = 0;
     const double time_start_total = get_time_ms();
 
     if (opt.resident) {
@@ -195,8 +197,36 @@ int main(int argc, char **argv)
             const int s = batch % nslots;
             // the buffer set was last used by batch - nslots: wait for exactly those submits
             if (batch >= nslots) {
-                if (cpu.ctx && cpu.submitted[batch - nslots]) mi_check(mi_blur_wait_oldest(cpu.ctx), "CPU wait failed");
-                for (auto &d : gpus) if (d.submitted[batch - nslots]) mi_check(mi_blur_wait_oldest(d.ctx), "GPU wait failed");
+                // "auto" keeps going after the first batch.  The device-time buckets the reference's recommendation is
+                // built on (:713-715) overlap in a pipelined host (H2D of one batch runs beside D2H of another), so they
+                // seed the ratio but cannot balance it.  What is balanced is what the host observes: which side it has
+                // to WAIT for.  The wait order alternates per batch; time blocked in the second wait is time that side
+                // finished after the other, and that fraction of the batch period moves to the other side.
+                const bool both_sides = cpu.ctx && !gpus.empty() && cpu.submitted[batch - nslots] && gpus[0].submitted[batch - nslots];
+                const bool cpu_first = (batch & 1) == 0;
+                double blocked[2] = {0, 0};
+                for (int k = 0; k < 2; k++) {
+                    const double w0 = get_time_ms();
+                    if ((k == 0) == cpu_first) {
+                        if (cpu.ctx && cpu.submitted[batch - nslots]) mi_check(mi_blur_wait_oldest(cpu.ctx), "CPU wait failed");
+                    } else {
+                        for (auto &d : gpus) if (d.submitted[batch - nslots]) mi_check(mi_blur_wait_oldest(d.ctx), "GPU wait failed");
+                    }
+                    blocked[k] = get_time_ms() - w0;
+                }
+                if (opt.auto_ratio && mode == 0 && both_sides) {
+                    const double now_ms = get_time_ms(), period = last_harvest_ms > 0 ? now_ms - last_harvest_ms : 0;
+                    // harvesting a finished GPU batch still costs tens of us (event queries): only a wait well above
+                    // that counts as lateness
+                    if (period > 0 && blocked[1] > std::max(0.10 * period, 0.05)) {
+                        const float shift = 0.25f * (float)std::min(1.0, blocked[1] / period) * (cpu_first ? gpu_ratio : 1.0f - gpu_ratio);
+                        gpu_ratio += cpu_first ? -shift : shift;     // second wait was the GPU's: it is the late side
+                        gpu_ratio = std::min(0.98f, std::max(0.02f, gpu_ratio));
+                        rebalances++;
+                        if (opt.verbose) printf("  Rebalanced GPU ratio: %.1f%%\n", gpu_ratio * 100);
+                    }
+                    last_harvest_ms = now_ms;
+                }
                 if (opt.save.size() && first_output.empty() && batch - nslots == 0)
                     first_output.assign(batch_output[s], batch_output[s] + image_size);
             }
@@ -246,6 +276,7 @@ int main(int argc, char **argv)
     const double time_end_total = get_time_ms();
     const double time_total_processing = time_end_total - time_start_total;
     printf("All batches finished!\n\n");
+    if (opt.auto_ratio && mode == 0) printf("Auto ratio after %d per-batch updates: %.1f%% GPU\n\n", rebalances, gpu_ratio * 100);
     if (opt.save.size() && !first_output.empty()) {
         save_one_image(opt.save.c_str(), first_output.data(), width, height, channels);
         printf("Saved example output: %s\n\n", opt.save.c_str());

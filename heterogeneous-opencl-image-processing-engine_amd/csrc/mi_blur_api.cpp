@@ -297,6 +297,13 @@ extern "C" int mi_blur_sync(mi_blur_ctx *c, mi_blur_timing *timing)
     return MI_BLUR_OK;
 }
 
+extern "C" int mi_blur_get_timing(mi_blur_ctx *c, mi_blur_timing *timing)
+{
+    if (!c || !timing) return MI_BLUR_ERR_INVALID;
+    *timing = c->tm;
+    return MI_BLUR_OK;
+}
+
 extern "C" void mi_blur_reset_timing(mi_blur_ctx *c)
 {
     if (!c) return;

@@ -160,6 +160,11 @@ int mi_blur_wait_oldest(mi_blur_ctx *ctx);
 /* clFinish + event harvest (heterogeneous_blur.c:538-579).  timing may be NULL. */
 int mi_blur_sync(mi_blur_ctx *ctx, mi_blur_timing *timing);
 void mi_blur_reset_timing(mi_blur_ctx *ctx);
+/* Non-blocking: the buckets of the submits harvested so far (by wait_oldest / sync).  A host that rotates
+ * batch buffers reads it after each mi_blur_wait_oldest to get that batch's device times — what the
+ * reference prints once per run (heterogeneous_blur.c:541-579) becomes available per batch, which is
+ * what continuous CPU/GPU rebalancing needs (`both auto`). */
+int mi_blur_get_timing(mi_blur_ctx *ctx, mi_blur_timing *timing);
 
 /* ------------------------------------------------------------------------
  * Device-resident stream (no reference analogue: the reference re-uploads

@@ -150,6 +150,8 @@ def test_cpu_context_submit_and_band(pkg, L, O):
         assert np.array_equal(out, O.blur_batch(img, 1))
         assert tm["images"] == 6 and tm["launches"] == 2 and tm["bytes_alg"] == 2 * img.size
         assert tm["kernel_ms"] > 0 and tm["h2d_ms"] == 0
+        assert ctx.timing() == tm                                   # non-blocking snapshot of the same buckets
+        assert L.mi_blur_get_timing(ctx.h, None) == pkg.ERR_INVALID
         # Approach 2 on the CPU device: top band [0, split+1) and bottom band [split-1, H)
         one = np.ascontiguousarray(img[0])
         whole = O.blur(one, 1)

@@ -110,6 +110,7 @@ def test_a1_gpu_and_both_modes(apps, O, tmp_path):
     assert np.array_equal(read_ppm(tmp_path / "both.ppm"), want)
     r = run([het, "both", "auto", "35", "--image", "in.ppm", "--images", "500", "--save", "auto.ppm"], tmp_path)
     assert r.returncode == 0 and "Auto-calibrated GPU ratio:" in r.stdout, r.stdout + r.stderr
+    assert "Auto ratio after" in r.stdout and "per-batch updates" in r.stdout, r.stdout    # keeps rebalancing per batch
     assert np.array_equal(read_ppm(tmp_path / "auto.ppm"), want)
     r = run([het, "gpu", "1.0", "35", "--size", "256x256", "--images", "5000", "--resident"], tmp_path)
     assert r.returncode == 0 and "9. MI355X KERNEL ROOFLINE" in r.stdout, r.stdout + r.stderr
