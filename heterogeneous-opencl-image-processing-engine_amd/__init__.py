@@ -135,6 +135,7 @@ def lib() -> C.CDLL:
         "mi_blur_sync": (i, [vp, C.POINTER(Timing)]),
         "mi_blur_reset_timing": (None, [vp]),
         "mi_blur_get_timing": (C.c_int, [vp, C.c_void_p]),
+        "mi_blur_zero_copy_launches": (C.c_uint64, [vp]),
         "mi_blur_resident_alloc": (i, [vp, i]),
         "mi_blur_resident_fill_synthetic": (i, [vp, i]),
         "mi_blur_resident_upload": (i, [vp, i, u8p, i]),

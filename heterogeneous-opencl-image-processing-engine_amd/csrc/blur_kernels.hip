@@ -514,7 +514,7 @@ __global__ __launch_bounds__(256) void blur_generic_kernel(const GenericParams p
 Tunables &tunables()
 {
     static Tunables t = [] {
-        Tunables v{1, 0, 1, 0, 0, 0, 0};  // rpg 0 / stream_bh 0 = choose per launch
+        Tunables v{1, 0, 1, 0, 0, 0, 0, 1};  // rpg 0 / stream_bh 0 = choose per launch
         if (const char *e = getenv("MI_BLUR_STAGE")) v.stage_dma = strcmp(e, "reg") != 0;
         if (const char *e = getenv("MI_BLUR_RPG")) { const int r = atoi(e); v.rpg = (r == 4 || r == 8 || r == 16) ? r : 0; }
         if (const char *e = getenv("MI_BLUR_XCD")) v.xcd_remap = atoi(e) != 0;
@@ -590,8 +590,8 @@ static int launch_tiled(const LaunchDesc &d)
 
     TiledParams p{};
     p.in = d.in; p.out = d.out;
-    p.in_stride = (long long)d.band_rows * pitch;
-    p.out_stride = (long long)rows * pitch;
+    p.in_stride = d.in_stride ? d.in_stride : (long long)d.band_rows * pitch;
+    p.out_stride = d.out_stride ? d.out_stride : (long long)rows * pitch;
     p.pitch = pitch; p.cpr = cpr; p.H = d.band_rows; p.y0 = d.y0; p.y1 = d.y1;
     p.nstrips = (cpr + 61) / 62;               // ncols + 2 halo chunks <= 64 lanes: one row per wave-instruction
     p.ncols = (cpr + p.nstrips - 1) / p.nstrips;
@@ -688,6 +688,15 @@ int launch(const LaunchDesc &d)
     if ((long long)d.width * d.channels * d.band_rows > INT_MAX) return MI_BLUR_ERR_INVALID;  // per-image 32-bit
     if (d.n_images == 0) return MI_BLUR_OK;
     const bool can_tile = tiled_eligible(d.in, d.out, d.width, d.channels);
+    const long long dense_in = (long long)d.band_rows * d.width * d.channels, dense_out = (long long)(d.y1 - d.y0) * d.width * d.channels;
+    if ((d.in_stride && d.in_stride != dense_in) || (d.out_stride && d.out_stride != dense_out)) {
+        // spaced-out bands (a caller's buffer used in place): tiled kernel only
+        if (d.in_stride < 0 || d.out_stride < 0 || (d.in_stride && d.in_stride < dense_in) || (d.out_stride && d.out_stride < dense_out))
+            return MI_BLUR_ERR_INVALID;
+        if (!can_tile || d.in_stride % 16 || d.out_stride % 16) return MI_BLUR_ERR_UNSUPPORTED;
+        if (d.variant != MI_BLUR_VARIANT_AUTO && d.variant != MI_BLUR_VARIANT_TILED) return MI_BLUR_ERR_UNSUPPORTED;
+        return launch_tiled(d);
+    }
     switch (d.variant) {
     case MI_BLUR_VARIANT_AUTO:
         if (!can_tile) return launch_generic(d);

@@ -12,6 +12,8 @@ struct LaunchDesc {
     int width, band_rows, channels, radius;
     int n_images;
     int y0, y1;             // output rows [y0,y1) of each band
+    long long in_stride, out_stride;  // bytes between consecutive bands / output blocks; 0 = laid end to end.
+                            // Non-dense strides are taken by the tiled kernel only (multiples of 16).
     int variant;            // mi_blur_variant
     hipStream_t stream;
     hipEvent_t start, stop; // optional: dispatch start/stop timestamps (hipExtLaunchKernel)
@@ -25,7 +27,7 @@ bool tiled_eligible(const void *in, const void *out, int width, int channels);
 
 // Tunables: defaults from env (MI_BLUR_STAGE=dma|reg, MI_BLUR_RPG=8|16, MI_BLUR_XCD=0|1),
 // changeable at run time through mi_blur_set_option.
-struct Tunables { int stage_dma; int rpg; int xcd_remap; int debug_copy; int row_shuffle; int prefer_stream; int stream_bh; };
+struct Tunables { int stage_dma; int rpg; int xcd_remap; int debug_copy; int row_shuffle; int prefer_stream; int stream_bh; int zero_copy; };
 Tunables &tunables();
 
 }  // namespace mi_blur

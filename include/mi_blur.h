@@ -66,7 +66,9 @@ int mi_blur_version(void);
  *   "xcd_remap"        1 = XCD-contiguous blockIdx->tile map (default), 0 = identity
  *   "row_shuffle"      1 = x-neighbour bytes by DPP wave shifts (LDS only at wave/tile edges), 0 = from LDS (default)
  *   "prefer_stream"    1 = AUTO picks the streaming variant instead of the tiled one (default 0)
- *   "stream_band_rows" streaming variant: output rows per wave (0 = chosen per launch) */
+ *   "stream_band_rows" streaming variant: output rows per wave (0 = chosen per launch)
+ *   "zero_copy"        1 (default) = submits whose input AND output are pinned host memory run the kernel on the
+ *                      caller's buffers in place (no staging copies); 0 = always H2D -> kernel -> D2H */
 int mi_blur_set_option(const char *key, int value);
 
 /* Number of visible HIP devices (0 is a valid answer: CPU-device contexts still work).
@@ -125,9 +127,13 @@ int mi_blur_create(mi_blur_ctx **out_ctx, int device, int width, int height, int
                    int radius, int max_batch, int n_slots, int n_threads);
 void mi_blur_destroy(mi_blur_ctx *ctx);
 
-/* Page-locked host memory for stream buffers.  submit() DMA-copies straight from/to
- * memory obtained here; ordinary (pageable) caller memory is accepted too and goes
- * through the slot's own pinned staging buffers (one extra host memcpy each way). */
+/* Page-locked, device-visible host memory for stream buffers.  When both buffers of a submit come
+ * from here (or are otherwise pinned) the kernel works on them in place over PCIe — the counterpart of
+ * CL_MEM_USE_HOST_PTR on the reference's shared-memory iGPU, and the fastest end-to-end form on this
+ * platform; the h2d/d2h buckets of such a submit are ~0 and the transfer time is inside kernel_ms.
+ * With only one side pinned, or "zero_copy" off, submit() DMA-copies straight from/to pinned memory;
+ * ordinary (pageable) caller memory is accepted too and goes through the slot's own pinned staging
+ * buffers (one extra host memcpy each way). */
 void *mi_blur_host_alloc(size_t bytes);
 void mi_blur_host_free(void *p);
 
@@ -165,6 +171,8 @@ void mi_blur_reset_timing(mi_blur_ctx *ctx);
  * reference prints once per run (heterogeneous_blur.c:541-579) becomes available per batch, which is
  * what continuous CPU/GPU rebalancing needs (`both auto`). */
 int mi_blur_get_timing(mi_blur_ctx *ctx, mi_blur_timing *timing);
+/* How many of the context's submits so far ran zero-copy (see mi_blur_host_alloc). */
+uint64_t mi_blur_zero_copy_launches(mi_blur_ctx *ctx);
 
 /* ------------------------------------------------------------------------
  * Device-resident stream (no reference analogue: the reference re-uploads

@@ -44,6 +44,7 @@ def reset_opts(L):
     L.mi_blur_set_option(b"row_shuffle", 0)
     L.mi_blur_set_option(b"stream_band_rows", 0)
     L.mi_blur_set_option(b"stage_dma", 1)
+    L.mi_blur_set_option(b"zero_copy", 1)
     L.mi_blur_set_option(b"rows_per_thread", 0)
     L.mi_blur_set_option(b"xcd_remap", 1)
 
@@ -222,16 +223,32 @@ def test_context_submit_pageable_and_pinned(pkg, L, O, torch_cuda):
         assert tm["images"] == n + 10 and tm["launches"] == 2
         assert tm["kernel_ms"] > 0 and tm["h2d_ms"] > 0 and tm["d2h_ms"] > 0
         assert tm["bytes_h2d"] == (n + 10) * h * w * c
-        # pinned caller memory: DMA straight from/to it
+        assert L.mi_blur_zero_copy_launches(ctx.h) == 0                      # pageable memory is always staged
+        # pinned caller memory: the kernel works on it in place (zero-copy, default) or DMA goes straight from/to it
         nbytes = host.nbytes
         p_in, p_out = L.mi_blur_host_alloc(nbytes), L.mi_blur_host_alloc(nbytes)
         assert p_in and p_out
         C.memmove(p_in, host.ctypes.data, nbytes)
-        ctx.submit(p_in, p_out, n)
-        ctx.sync()
-        got = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(p_out)).reshape(host.shape).copy()
+        try:
+            for zc in (1, 0):
+                pkg.check(L.mi_blur_set_option(b"zero_copy", zc))
+                C.memset(p_out, 0, nbytes)
+                before = L.mi_blur_zero_copy_launches(ctx.h)
+                ctx.reset_timing()
+                ctx.submit(p_in, p_out, n)
+                ctx.submit(p_in, p_out, 10)                                  # chained behind the first
+                tm = ctx.sync()
+                got = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(p_out)).reshape(host.shape).copy()
+                assert np.array_equal(got, want), zc
+                assert L.mi_blur_zero_copy_launches(ctx.h) - before == (2 if zc else 0)
+                assert tm["bytes_h2d"] == (n + 10) * h * w * c and tm["kernel_ms"] > 0
+                if zc:
+                    assert tm["h2d_ms"] < 0.25 * tm["kernel_ms"] and tm["d2h_ms"] < 0.25 * tm["kernel_ms"]
+                # input untouched by the in-place read
+                assert np.array_equal(np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(p_in)).reshape(host.shape), host)
+        finally:
+            pkg.check(L.mi_blur_set_option(b"zero_copy", 1))
         L.mi_blur_host_free(p_in); L.mi_blur_host_free(p_out)
-        assert np.array_equal(got, want)
         # Approach-2 bands through the context
         one = np.ascontiguousarray(host[0]); split = 39
         top, bot = np.zeros((split, w, c), np.uint8), np.zeros((h - split, w, c), np.uint8)
@@ -248,8 +265,9 @@ def test_submit_bands_strided_batch(pkg, L, O, torch_cuda):
     host = O.lcg_stream(n, h, w, c)
     want = O.blur_batch(host, 1)
     pitch, isz = w * c, h * w * c
-    for pinned in (False, True):
+    for pinned in (False, True, "staged"):
         for n_slots in (1, 3):
+            pkg.check(L.mi_blur_set_option(b"zero_copy", 0 if pinned == "staged" else 1))
             with pkg.Context(0, w, h, c, 1, max_batch=n, n_slots=n_slots) as ctx:
                 if pinned:
                     p_in, p_out = L.mi_blur_host_alloc(host.nbytes), L.mi_blur_host_alloc(host.nbytes)
@@ -264,12 +282,15 @@ def test_submit_bands_strided_batch(pkg, L, O, torch_cuda):
                                                  h - split + 1, 1, 0), "submit_bands bottom")
                 tm = ctx.sync()
                 assert tm["launches"] == 2 and tm["images"] == 2 * n
+                # pinned + zero_copy: the strided bands are blurred in place in the caller's batch buffers
+                assert L.mi_blur_zero_copy_launches(ctx.h) == (2 if pinned is True else 0)
                 if pinned:
                     got = np.ctypeslib.as_array((C.c_uint8 * host.nbytes).from_address(p_out)).reshape(host.shape).copy()
                     L.mi_blur_host_free(p_in); L.mi_blur_host_free(p_out)
                 else:
                     got = out
                 assert np.array_equal(got, want), (pinned, n_slots)
+    pkg.check(L.mi_blur_set_option(b"zero_copy", 1))
 
 
 def test_resident_stream(pkg, L, O, torch_cuda):
