@@ -139,7 +139,9 @@ def main() -> None:
     ap.add_argument("--workload", choices=["a1", "hd5", "a2"], default="a1")
     ap.add_argument("--batch", type=int, default=35)
     ap.add_argument("--images", type=int, default=5000, help="images per GPU per step (a1)")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("MI_BLUR_BENCH_STREAMS", "4")))
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("MI_BLUR_BENCH_STREAMS", "0")),
+                    help="HIP streams the launches alternate over (default: 4 for a1 — small launches whose dispatch floors "
+                         "must overlap — and 1 for hd5, whose launches fill the GPU on their own)")
     ap.add_argument("--time-every", type=int, default=32,
                     help="a1: every n-th launch of the timed region carries dispatch timestamp events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -188,6 +190,8 @@ def main() -> None:
             dist_barrier()
         torch.cuda.synchronize()
 
+    if args.streams <= 0:
+        args.streams = 4 if args.workload == "a1" else 1
     extra = {}
     extra_serial = None
     if args.workload in ("a1", "hd5"):
