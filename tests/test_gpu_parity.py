@@ -56,7 +56,7 @@ def want_batch(O, host, radius):
 # shapes: (H, W, C).  pitch % 16 == 0 -> tiled kernel eligible; the rest exercise the generic kernel.
 TILED_SHAPES = [(16, 16, 3), (1, 16, 1), (2, 16, 3), (3, 32, 2), (5, 64, 4), (9, 48, 3), (33, 80, 3), (64, 80, 3),
                 (240, 320, 3), (256, 256, 3), (47, 1360, 3), (40, 4096, 1), (31, 1040, 4), (100, 16, 4),
-                (131, 112, 1), (17, 2064, 2)]
+                (131, 112, 1), (17, 2064, 2), (2, 262144, 1), (1, 65536, 4)]
 GENERIC_SHAPES = [(1, 1, 3), (3, 5, 3), (33, 17, 3), (33, 17, 1), (31, 29, 4), (2, 2, 3), (64, 1, 3), (1, 64, 3),
                   (7, 9, 5), (50, 37, 2)]
 
@@ -291,6 +291,33 @@ def test_submit_bands_strided_batch(pkg, L, O, torch_cuda):
                     got = out
                 assert np.array_equal(got, want), (pinned, n_slots)
     pkg.check(L.mi_blur_set_option(b"zero_copy", 1))
+
+
+def test_batch_beyond_4gib(pkg, L, O, torch_cuda):
+    """One launch over a batch whose input and output each exceed 4 GiB (22 000 x 256x256x3 = 4.33 GB): image offsets
+    must be 64-bit in every variant.  Checked on the images either side of the 2^32-byte line, the first and the
+    last, against the oracle; and the three variants must agree on the whole output."""
+    torch = torch_cuda
+    h, w, c, n = 256, 256, 3, 22000
+    isz = h * w * c
+    assert n * isz > (1 << 32)
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    d_in = torch.randint(0, 256, (n, h, w, c), dtype=torch.uint8, device="cuda", generator=g)
+    edge = (1 << 32) // isz
+    sample = [0, 1, edge - 1, edge, edge + 1, n - 2, n - 1]
+    want = {i: O.blur(np.ascontiguousarray(d_in[i].cpu().numpy()), 1) for i in sample}
+    outs = []
+    try:
+        for variant in (pkg.VARIANT_TILED, pkg.VARIANT_STREAM, pkg.VARIANT_GENERIC):
+            d_out = torch.zeros_like(d_in)
+            pkg.check(L.mi_blur_enqueue_ex(d_in.data_ptr(), d_out.data_ptr(), w, h, c, 1, n, 0, h, variant, None))
+            torch.cuda.synchronize()
+            for i in sample:
+                assert np.array_equal(d_out[i].cpu().numpy(), want[i]), (variant, i)
+            outs.append(d_out)
+        assert bool((outs[0] == outs[1]).all()) and bool((outs[0] == outs[2]).all())
+    finally:
+        reset_opts(L)
 
 
 def test_resident_stream(pkg, L, O, torch_cuda):
