@@ -175,12 +175,20 @@ int main(int argc, char **argv)
     const double time_start_total = get_time_ms();
 
     if (opt.resident) {
+        // one host thread per GPU: a stream of batch-35 launches is issue-rate-bound, so one thread feeding
+        // G GPUs in turn would serialise them
+        std::vector<std::thread> feeders;
+        std::vector<int> feed_rc(G, MI_BLUR_OK);
         for (int g = 0; g < G; g++) {
             long long b, e;
             mi_blur_shard_range(NUM_IMAGES, g, G, &b, &e);
-            mi_check(mi_blur_resident_run(gpus[g].ctx, (int)(e - b), BATCH_SIZE, resident_timed_every), "resident run failed");
             total_images_gpu += (int)(e - b);
+            feeders.emplace_back([&, g, b, e]() {
+                feed_rc[g] = mi_blur_resident_run(gpus[g].ctx, (int)(e - b), BATCH_SIZE, resident_timed_every);
+            });
         }
+        for (auto &t : feeders) t.join();
+        for (int g = 0; g < G; g++) mi_check(feed_rc[g], "resident run failed");
         for (int g = 0; g < G; g++) {
             mi_check(mi_blur_sync(gpus[g].ctx, &gpus[g].tm), "GPU sync failed");
             uint64_t timed = 0;
