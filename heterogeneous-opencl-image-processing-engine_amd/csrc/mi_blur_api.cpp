@@ -186,7 +186,9 @@ extern "C" void *mi_blur_host_alloc(size_t bytes)
 {
     void *p = nullptr;
     if (mi_blur_device_count() > 0) {
-        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess) return p;
+        // portable + mapped: visible to every GPU's contexts (A1 hands one batch buffer to G devices, each of which
+        // may work on its share in place)
+        if (hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess) return p;
         (void)hipGetLastError();
         return nullptr;
     }
