@@ -23,13 +23,15 @@ int main(int argc, char **argv)
     std::vector<uint8_t> want(bytes);
 
     struct Flag { const char *name; unsigned in, out; };
-    const Flag flags[] = {
+    const Flag all_flags[] = {
         {"default/default", hipHostMallocDefault, hipHostMallocDefault},
         {"noncoherent/noncoherent", hipHostMallocNonCoherent, hipHostMallocNonCoherent},
         {"coherent/coherent", hipHostMallocCoherent, hipHostMallocCoherent},
         {"writecombined-in/default", hipHostMallocWriteCombined, hipHostMallocDefault},
         {"noncoherent+wc-in/noncoherent", hipHostMallocNonCoherent | hipHostMallocWriteCombined, hipHostMallocNonCoherent},
     };
+    const int nflags = argc > 4 ? atoi(argv[4]) : 5;      // 4th argument: how many flag sets to try
+    std::vector<Flag> flags(all_flags, all_flags + (nflags < 5 ? nflags : 5));
     bool have_want = false;
     for (const Flag &f : flags) {
         uint8_t *hin = nullptr, *hout = nullptr;
@@ -53,11 +55,16 @@ int main(int argc, char **argv)
         CK(hipStreamSynchronize(st));
         const double t_staged = (now_us() - t0) / reps;
         printf("%-32s staged              %8.1f us/batch %7.1f k img/s\n", f.name, t_staged, n / t_staged * 1e3);
-        struct Opt { const char *name; int rpt, stream; };
-        const Opt opts[] = {{"tiled auto", 0, 0}, {"tiled rows/thread 4", 4, 0}, {"tiled rows/thread 8", 8, 0}, {"tiled rows/thread 16", 16, 0}, {"stream variant", 0, 1}};
+        struct Opt { const char *name; int rpt, stream, dma, xcd; };
+        const Opt opts[] = {{"tiled auto", 0, 0, 1, 1}, {"tiled rows/thread 4", 4, 0, 1, 1}, {"tiled rows/thread 8", 8, 0, 1, 1},
+                            {"tiled rows/thread 16", 16, 0, 1, 1}, {"stream variant", 0, 1, 1, 1},
+                            {"tiled, register staging", 0, 0, 0, 1}, {"tiled, identity tile map", 0, 0, 1, 0},
+                            {"tiled, reg staging + identity", 0, 0, 0, 0}};
         for (const Opt &o : opts) {
             mi_blur_set_option("rows_per_thread", o.rpt);
             mi_blur_set_option("prefer_stream", o.stream);
+            mi_blur_set_option("stage_dma", o.dma);
+            mi_blur_set_option("xcd_remap", o.xcd);
             memset(hout, 0, bytes);
             MK(mi_blur_enqueue(hin, hout, W, H, C, R, n, st));
             CK(hipStreamSynchronize(st));
@@ -71,6 +78,8 @@ int main(int argc, char **argv)
         }
         mi_blur_set_option("rows_per_thread", 0);
         mi_blur_set_option("prefer_stream", 0);
+        mi_blur_set_option("stage_dma", 1);
+        mi_blur_set_option("xcd_remap", 1);
         CK(hipHostFree(hin)); CK(hipHostFree(hout));
     }
     return 0;
