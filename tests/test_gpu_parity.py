@@ -495,3 +495,46 @@ def test_multi_stream_soak(pkg, L, O, torch_cuda):
         for idx in [0, 34, 35, n - 1] + [int(x) for x in rng.integers(0, n, 12)]:
             ctx.resident_download(idx, got.ctypes.data, 1)
             assert np.array_equal(got[0], O.blur(O.lcg_stream(1, h, w, c, first_index=100 + idx)[0], 1)), idx
+
+
+def test_contexts_driven_from_concurrent_host_threads(pkg, L, O, torch_cuda):
+    """include/mi_blur.h: a context is single-threaded, different contexts may be driven from different host threads
+    at the same time (one feeder thread per GPU in the hosts).  Three threads, three contexts of different shapes and
+    radii on the same device, each mixing pageable submits, zero-copy submits and resident passes."""
+    import threading
+    specs = [(96, 128, 3, 1, 11), (64, 80, 4, 2, 7), (120, 48, 1, 1, 9)]
+    errors = []
+
+    def drive(k, h, w, c, r, n):
+        try:
+            host = O.lcg_stream(n, h, w, c, first_index=1000 * k)
+            want = O.blur_batch(host, r)
+            nbytes = host.nbytes
+            with pkg.Context(0, w, h, c, r, max_batch=n, n_slots=2) as ctx:
+                p_in, p_out = L.mi_blur_host_alloc(nbytes), L.mi_blur_host_alloc(nbytes)
+                C.memmove(p_in, host.ctypes.data, nbytes)
+                ctx.resident_alloc(n)
+                ctx.resident_upload(0, host.ctypes.data, n)
+                for rep in range(25):
+                    out = np.zeros_like(host)
+                    ctx.submit(host.ctypes.data, out.ctypes.data, n)            # staged
+                    C.memset(p_out, 0, nbytes)
+                    ctx.submit(p_in, p_out, n)                                  # zero-copy
+                    ctx.resident_run(n, max(1, n // 2), timed=1)
+                    ctx.sync()
+                    got = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(p_out)).reshape(host.shape)
+                    res = np.zeros_like(host)
+                    ctx.resident_download(0, res.ctypes.data, n)
+                    if not (np.array_equal(out, want) and np.array_equal(got, want) and np.array_equal(res, want)):
+                        errors.append((k, rep))
+                        break
+                L.mi_blur_host_free(p_in); L.mi_blur_host_free(p_out)
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=drive, args=(k,) + s) for k, s in enumerate(specs)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
