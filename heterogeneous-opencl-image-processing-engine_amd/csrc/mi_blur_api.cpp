@@ -263,12 +263,18 @@ extern "C" int mi_blur_create(mi_blur_ctx **out_ctx, int device, int width, int 
 static int finish_slot(mi_blur_ctx *c, Slot &s)
 {
     if (!s.busy) return MI_BLUR_OK;
-    if (s.zero_copy) HIP_TRY(hipEventSynchronize(s.ev[3]));     // launched on the context's zero-copy stream, not the slot's
-    else HIP_TRY(hipStreamSynchronize(s.stream));
-    s.zero_copy = false;
+    float ms = 0.f;
+    if (s.zero_copy) {                                           // launched on the context's zero-copy stream, not the slot's
+        HIP_TRY(hipEventSynchronize(s.ke));
+        if (hipEventElapsedTime(&ms, s.ks, s.ke) == hipSuccess) c->tm.kernel_ms += ms;
+        (void)hipGetLastError();
+        s.zero_copy = false;
+        s.busy = false;
+        return MI_BLUR_OK;
+    }
+    HIP_TRY(hipStreamSynchronize(s.stream));
     if (s.out_staged)
         for (int i = 0; i < s.out_n; i++) memcpy(s.user_out + (size_t)i * s.out_stride, s.h_out + (size_t)i * s.out_band, s.out_band);
-    float ms = 0.f;
     if (hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) c->tm.h2d_ms += ms;
     if (hipEventElapsedTime(&ms, s.ks, s.ke) == hipSuccess) c->tm.kernel_ms += ms;
     if (hipEventElapsedTime(&ms, s.ev[2], s.ev[3]) == hipSuccess) c->tm.d2h_ms += ms;
@@ -395,9 +401,9 @@ static int submit_common(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_o
                 s.out_staged = false; s.user_out = host_out; s.out_bytes = out_bytes; s.out_band = band_out; s.out_stride = out_stride;
                 s.out_n = n_images;
                 const hipStream_t zs = c->slots[0].stream;     // all zero-copy launches of a context: one in-order stream
-                s.zero_copy = true;
-                HIP_TRY(hipEventRecord(s.ev[0], zs));
-                HIP_TRY(hipEventRecord(s.ev[1], zs));
+                s.zero_copy = true;                            // one dispatch packet, nothing else: the kernel's own stop
+                                                               // event doubles as the completion event (every extra
+                                                               // hipEventRecord is a barrier packet between two kernels)
                 LaunchDesc d{};
                 d.in = zin; d.out = zout; d.width = c->W; d.band_rows = band_rows; d.channels = c->C;
                 d.radius = c->R; d.n_images = n_images; d.y0 = y0; d.y1 = y1; d.variant = MI_BLUR_VARIANT_AUTO;
@@ -405,8 +411,6 @@ static int submit_common(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_o
                 d.stream = zs; d.start = s.ks; d.stop = s.ke;
                 rc = launch(d);
                 if (rc) return rc;
-                HIP_TRY(hipEventRecord(s.ev[2], zs));
-                HIP_TRY(hipEventRecord(s.ev[3], zs));
                 s.busy = true;
                 c->tm.bytes_h2d += in_bytes; c->tm.bytes_d2h += out_bytes;
                 c->tm.bytes_alg += 2ull * out_bytes;
