@@ -166,6 +166,8 @@ struct Options {
     std::string save;                    // --save FILE  write the first output image
     int iters = 100;                     // --iters N    (split_image_blur --resident)
     bool iterate = false;                // --iterate    (split_image_blur --resident): blur the previous iteration's output
+    bool overlap = false;                // --overlap    (split_image_blur --resident): halo exchange on its own stream, hidden
+                                         //              behind the blur of the interior rows; edge rows follow it
     std::string transport = "rccl";      // --transport rccl|p2p  (split_image_blur --resident): halo rows by RCCL or peer copies
     bool auto_ratio = false;             // gpu_ratio given as "auto": calibrate on the first batches (heterogeneous_blur both)
     bool size_given = false;
@@ -198,6 +200,7 @@ inline int parse_flags(int argc, char **argv, Options &o)
         else if (a == "--save") o.save = next("--save");
         else if (a == "--iters") o.iters = atoi(next("--iters"));
         else if (a == "--iterate") o.iterate = true;
+        else if (a == "--overlap") o.overlap = true;
         else if (a == "--transport") { o.transport = next("--transport"); if (o.transport != "rccl" && o.transport != "p2p") { printf("Error: --transport rccl|p2p\n"); exit(-1); } }
         else { printf("Error: unknown option %s\n", a.c_str()); exit(-1); }
     }

@@ -2,7 +2,8 @@
 //
 //   split_image_blur [gpu_ratio] [batch]  [--image F | --synthetic | --size WxH] [--channels C] [--ksize 3|5]
 //                    [--images N] [--gpus G] [--slots S] [--threads T] [--verbose] [--csv FILE] [--save FILE]
-//   split_image_blur --resident [--gpus G] [--size WxH] [--ksize 3|5] [--iters N] [--iterate] [--save FILE]
+//   split_image_blur --resident [--gpus G] [--size WxH] [--ksize 3|5] [--iters N] [--iterate] [--overlap]
+//                    [--transport rccl|p2p] [--save FILE]
 //
 // Default mode keeps the reference host's semantics (split_image_blur.c:62-102 CLI, :142-173
 // geometry, :441-607 batch loop, :615-721 report): every image is split at
@@ -294,7 +295,50 @@ static int run_resident(const Options &opt)
                              (size_t)owned[g] * pitch, hipMemcpyHostToDevice));
         }
     };
+    // --overlap: the exchange runs on its own stream per GPU while the compute stream blurs the interior rows
+    // [R, owned-R) of the shard, which need no halo; the 2R edge rows are blurred once the halos have arrived.  Events:
+    // ev_done[g] = GPU g finished the previous step (its edge rows are final, its halo rows are free to overwrite),
+    // ev_halo[g] = this step's halos of GPU g are in place.
+    std::vector<hipStream_t> xstream(G, nullptr);
+    std::vector<hipEvent_t> ev_done(G, nullptr), ev_halo(G, nullptr);
+    bool overlap = opt.overlap && G > 1;
+    for (int g = 0; g < G && overlap; g++) if (owned[g] <= 2 * radius) overlap = false;     // no interior to hide behind
+    if (overlap)
+        for (int g = 0; g < G; g++) {
+            HIP_OK(hipSetDevice(devs[g]));
+            HIP_OK(hipStreamCreateWithFlags(&xstream[g], hipStreamNonBlocking));
+            HIP_OK(hipEventCreateWithFlags(&ev_done[g], hipEventDisableTiming));
+            HIP_OK(hipEventCreateWithFlags(&ev_halo[g], hipEventDisableTiming));
+            HIP_OK(hipEventRecord(ev_done[g], stream[g]));
+        }
+    if (opt.overlap) printf("Overlap: %s\n", overlap ? "halo exchange hidden behind the interior rows" : "not applicable (one GPU or shards without interior)");
+    auto step_overlapped = [&]() {
+        std::vector<void *> xs(G);
+        for (int g = 0; g < G; g++) {
+            xs[g] = xstream[g];
+            HIP_OK(hipSetDevice(devs[g]));
+            HIP_OK(hipStreamWaitEvent(xstream[g], ev_done[g], 0));
+        }
+        mi_check(mi_blur_halo_exchange_all(comm.data(), G, d_band.data(), W, C, owned.data(), radius, xs.data()), "halo exchange failed");
+        for (int g = 0; g < G; g++) {
+            HIP_OK(hipSetDevice(devs[g]));
+            HIP_OK(hipEventRecord(ev_halo[g], xstream[g]));
+            const int ht = band[g].halo_top, rows = owned[g] + ht + band[g].halo_bottom;
+            uint8_t *dst = opt.iterate ? d_band2[g] + (size_t)ht * pitch : d_out[g];
+            // interior first (reads no halo row), then — after the halos — the edges.  An edge that is the image's own
+            // edge (no neighbour) needs no halo either, but keeping the two-phase form per GPU keeps the code uniform.
+            mi_check(mi_blur_enqueue_band(d_band[g], dst + (size_t)radius * pitch, W, rows, C, radius, ht + radius, ht + owned[g] - radius,
+                                          stream[g]), "interior launch failed");
+            HIP_OK(hipStreamWaitEvent(stream[g], ev_halo[g], 0));
+            mi_check(mi_blur_enqueue_band(d_band[g], dst, W, rows, C, radius, ht, ht + radius, stream[g]), "top edge launch failed");
+            mi_check(mi_blur_enqueue_band(d_band[g], dst + (size_t)(owned[g] - radius) * pitch, W, rows, C, radius,
+                                          ht + owned[g] - radius, ht + owned[g], stream[g]), "bottom edge launch failed");
+            HIP_OK(hipEventRecord(ev_done[g], stream[g]));
+        }
+        if (opt.iterate) std::swap(d_band, d_band2);
+    };
     auto step = [&]() {
+        if (overlap) { step_overlapped(); return; }
         std::vector<void *> st(G);
         for (int g = 0; g < G; g++) st[g] = stream[g];
         mi_check(mi_blur_halo_exchange_all(comm.data(), G, d_band.data(), W, C, owned.data(), radius, st.data()), "halo exchange failed");
@@ -306,7 +350,13 @@ static int run_resident(const Options &opt)
         }
         if (opt.iterate) std::swap(d_band, d_band2);     // the blurred shard is the next iteration's input
     };
-    auto sync_all = [&]() { for (int g = 0; g < G; g++) { HIP_OK(hipSetDevice(devs[g])); HIP_OK(hipStreamSynchronize(stream[g])); } };
+    auto sync_all = [&]() {
+        for (int g = 0; g < G; g++) {
+            HIP_OK(hipSetDevice(devs[g]));
+            HIP_OK(hipStreamSynchronize(stream[g]));
+            if (xstream[g]) HIP_OK(hipStreamSynchronize(xstream[g]));
+        }
+    };
     step(); sync_all();                                  // warm-up (also first RCCL connection set-up)
     if (opt.iterate) upload();                           // start the timed chain from the original image again
     const double t0 = get_time_ms();
@@ -351,6 +401,7 @@ static int run_resident(const Options &opt)
         mi_blur_comm_destroy(comm[g]);
         HIP_OK(hipFree(d_band[g])); HIP_OK(hipFree(d_out[g])); HIP_OK(hipStreamDestroy(stream[g]));
         if (d_band2[g]) HIP_OK(hipFree(d_band2[g]));
+        if (xstream[g]) { HIP_OK(hipStreamDestroy(xstream[g])); HIP_OK(hipEventDestroy(ev_done[g])); HIP_OK(hipEventDestroy(ev_halo[g])); }
     }
     return same ? 0 : 1;
 }

@@ -214,3 +214,13 @@ def test_resident_row_shards_on_virtual_gpus(apps, O, tmp_path):
         for _ in range(4):
             want = O.blur(want, radius)
         assert np.array_equal(read_ppm(tmp_path / "it.ppm"), want)
+        # the same with the exchange on its own stream, hidden behind the interior rows (edge rows follow the halos)
+        for extra, fname, passes in ((["--iterate"], "ov_it.ppm", 5), ([], "ov_one.ppm", 1)):
+            r = subprocess.run([spl, "--resident", "--overlap", "--gpus", "4", "--size", "320x240", "--ksize", ksize, "--iters", "5",
+                                "--save", fname] + extra, cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
+            assert r.returncode == 0 and "EQUALS the single-device blur" in r.stdout, r.stdout + r.stderr
+            assert "halo exchange hidden behind the interior rows" in r.stdout
+            want = src
+            for _ in range(passes):
+                want = O.blur(want, radius)
+            assert np.array_equal(read_ppm(tmp_path / fname), want), (ksize, extra)
