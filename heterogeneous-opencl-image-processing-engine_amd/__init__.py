@@ -42,7 +42,7 @@ def _newer(target: str, sources: list[str]) -> bool:
 
 def build_native(force: bool = False, verbose: bool = False) -> str:
     """Compile libmi_blur.so (hipcc, --offload-arch=gfx950) and the C++ hosts, in-tree."""
-    srcs = [os.path.join(CSRC, f) for f in ("blur_kernels.hip", "mi_blur_api.cpp", "cpu_device.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("blur_kernels.hip", "layout_kernels.hip", "mi_blur_api.cpp", "cpu_device.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in ("blur_launch.h", "cpu_device.h")] + [HEADER]
     if force or not _newer(LIB_PATH, deps):
         cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra",
@@ -124,6 +124,8 @@ def lib() -> C.CDLL:
         "mi_blur_enqueue": (i, [u8p, u8p, i, i, i, i, i, vp]),
         "mi_blur_enqueue_band": (i, [u8p, u8p, i, i, i, i, i, i, vp]),
         "mi_blur_enqueue_ex": (i, [u8p, u8p, i, i, i, i, i, i, i, i, vp]),
+        "mi_blur_planar_to_interleaved": (i, [u8p, u8p, i, i, i, i, vp]),
+        "mi_blur_interleaved_to_planar": (i, [u8p, u8p, i, i, i, i, vp]),
         "mi_blur_create": (i, [C.POINTER(vp), i, i, i, i, i, i, i, i]),
         "mi_blur_destroy": (None, [vp]),
         "mi_blur_host_alloc": (vp, [C.c_size_t]),

@@ -22,6 +22,10 @@ struct LaunchDesc {
 // Returns MI_BLUR_OK or a negative mi_blur_status.
 int launch(const LaunchDesc &d);
 
+// Planar (CImg storage: plane c of image i at (i*C + c)*W*H) <-> interleaved repack, layout_kernels.hip.
+int launch_planar_to_interleaved(const uint8_t *src, uint8_t *dst, int width, int height, int channels, int n_images, hipStream_t s);
+int launch_interleaved_to_planar(const uint8_t *src, uint8_t *dst, int width, int height, int channels, int n_images, hipStream_t s);
+
 // True when the LDS-tiled vector kernel can take this shape.
 bool tiled_eligible(const void *in, const void *out, int width, int channels);
 

@@ -119,6 +119,21 @@ extern "C" int mi_blur_enqueue_band(const uint8_t *d_in, uint8_t *d_out, int wid
                               MI_BLUR_VARIANT_AUTO, stream);
 }
 
+// Frame layout on the device (replaces the host loops heterogeneous_blur.c:125-134 and split_image_blur.c:40-56).
+extern "C" int mi_blur_planar_to_interleaved(const uint8_t *d_planar, uint8_t *d_interleaved, int width, int height,
+                                             int channels, int n_images, void *stream)
+{
+    if (mi_blur_device_count() <= 0) return MI_BLUR_ERR_NO_DEVICE;
+    return launch_planar_to_interleaved(d_planar, d_interleaved, width, height, channels, n_images, (hipStream_t)stream);
+}
+
+extern "C" int mi_blur_interleaved_to_planar(const uint8_t *d_interleaved, uint8_t *d_planar, int width, int height,
+                                             int channels, int n_images, void *stream)
+{
+    if (mi_blur_device_count() <= 0) return MI_BLUR_ERR_NO_DEVICE;
+    return launch_interleaved_to_planar(d_interleaved, d_planar, width, height, channels, n_images, (hipStream_t)stream);
+}
+
 // ----------------------------------------------------------------------------------
 // queue level
 // ----------------------------------------------------------------------------------

@@ -175,6 +175,21 @@ int mi_blur_get_timing(mi_blur_ctx *ctx, mi_blur_timing *timing);
 uint64_t mi_blur_zero_copy_launches(mi_blur_ctx *ctx);
 
 /* ------------------------------------------------------------------------
+ * Frame layout on the device.  CImg (the reference's image loader) stores frames
+ * PLANAR — byte (x, y, c) of image i at (i*C + c)*W*H + y*W + x — and the
+ * reference repacks each frame to the interleaved stream on one host core
+ * (heterogeneous_blur.c:125-134; back again to save, split_image_blur.c:40-56).
+ * These do the same repack for n_images frames in one HBM pass each way.
+ * Buffers are device (or pinned host) memory, distinct, n_images*W*H*C bytes.
+ * (No repack at all is needed to BLUR planar frames: a planar stream is a stream
+ * of n_images*C one-channel images — mi_blur_enqueue(..., channels = 1, n*C).)
+ * ---------------------------------------------------------------------- */
+int mi_blur_planar_to_interleaved(const uint8_t *d_planar, uint8_t *d_interleaved, int width, int height,
+                                  int channels, int n_images, void *stream);
+int mi_blur_interleaved_to_planar(const uint8_t *d_interleaved, uint8_t *d_planar, int width, int height,
+                                  int channels, int n_images, void *stream);
+
+/* ------------------------------------------------------------------------
  * Device-resident stream (no reference analogue: the reference re-uploads
  * every image).  The pool holds pool_images images in HBM (in + out).
  * ---------------------------------------------------------------------- */

@@ -58,6 +58,8 @@ def lib() -> C.CDLL:
         L.oracle_a2_geometry.argtypes = [C.c_int, C.c_float, C.c_int, C.POINTER(_Geom)]
         L.oracle_a2_split_blur.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.oracle_splitk_blur.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.oracle_planar_to_interleaved.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.oracle_interleaved_to_planar.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.oracle_lcg_fill.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32]
         L.oracle_fnv1a64.argtypes = [C.c_void_p, C.c_size_t]
         L.oracle_fnv1a64.restype = C.c_uint64
@@ -148,6 +150,23 @@ def splitk_blur(img: np.ndarray, k: int, radius: int = 1) -> np.ndarray:
     rc = lib().oracle_splitk_blur(_p(img), _p(out), w, h, c, k, radius)
     if rc:
         raise ValueError(f"oracle_splitk_blur rc={rc}")
+    return out
+
+
+def planar_to_interleaved(planar: np.ndarray) -> np.ndarray:
+    """planar: (C, H, W) uint8 (CImg storage) -> (H, W, C) interleaved, heterogeneous_blur.c:125-134."""
+    assert planar.dtype == np.uint8 and planar.ndim == 3 and planar.flags.c_contiguous
+    c, h, w = planar.shape
+    out = np.empty((h, w, c), np.uint8)
+    lib().oracle_planar_to_interleaved(_p(planar), _p(out), w, h, c)
+    return out
+
+
+def interleaved_to_planar(img: np.ndarray) -> np.ndarray:
+    """(H, W, C) interleaved -> (C, H, W) planar, split_image_blur.c:40-56."""
+    h, w, c = _chk(img)
+    out = np.empty((c, h, w), np.uint8)
+    lib().oracle_interleaved_to_planar(_p(img), _p(out), w, h, c)
     return out
 
 

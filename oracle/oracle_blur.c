@@ -203,6 +203,31 @@ int oracle_splitk_blur(const uint8_t *in, uint8_t *out, int width, int height, i
 }
 
 /* ------------------------------------------------------------------------
+ * Frame layout.  The reference loads frames through CImg (planar storage:
+ * byte (x, y, c) at c*W*H + y*W + x, CImg.h `operator()(x,y,z,c)`) and repacks
+ * them to the interleaved stream with the loop at heterogeneous_blur.c:125-134
+ * (idx = (y*width + x)*channels; out[idx + c] = img(x, y, 0, c)); the inverse
+ * loop is split_image_blur.c:40-56.  Restated for any channel count.
+ * ---------------------------------------------------------------------- */
+void oracle_planar_to_interleaved(const uint8_t *planar, uint8_t *interleaved, int W, int H, int C)
+{
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const size_t idx = ((size_t)y * W + x) * C;
+            for (int c = 0; c < C; c++) interleaved[idx + c] = planar[(size_t)c * W * H + (size_t)y * W + x];
+        }
+}
+
+void oracle_interleaved_to_planar(const uint8_t *interleaved, uint8_t *planar, int W, int H, int C)
+{
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const size_t idx = ((size_t)y * W + x) * C;
+            for (int c = 0; c < C; c++) planar[(size_t)c * W * H + (size_t)y * W + x] = interleaved[idx + c];
+        }
+}
+
+/* ------------------------------------------------------------------------
  * Synthetic stream + hashing: LCG s = s*1664525+1013904223
  * (mod 2^32), byte = s>>24, filled in memory order; FNV-1a-64.
  * ---------------------------------------------------------------------- */

@@ -538,3 +538,57 @@ def test_contexts_driven_from_concurrent_host_threads(pkg, L, O, torch_cuda):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("c", [1, 2, 3, 4, 5])
+def test_layout_repack_matches_reference_loops(pkg, L, O, torch_cuda, c):
+    """mi_blur_planar_to_interleaved / _interleaved_to_planar == the reference's host loops
+    (heterogeneous_blur.c:125-134, split_image_blur.c:40-56), for the 16-pixel vector path (W*H % 16 == 0, C <= 4), the
+    byte path (ragged sizes, C = 5, unaligned pointers), batches, and as a round trip at a BASELINE size."""
+    torch = torch_cuda
+    rng = np.random.default_rng(40 + c)
+    for (h, w, n) in [(4, 4, 1), (16, 16, 3), (240, 320, 5), (7, 9, 2), (1, 1, 4), (33, 48, 2)]:
+        planar = rng.integers(0, 256, (n, c, h, w), dtype=np.uint8)
+        want = np.stack([O.planar_to_interleaved(np.ascontiguousarray(planar[i])) for i in range(n)])
+        d_p = torch.from_numpy(planar).cuda()
+        d_i = torch.zeros((n, h, w, c), dtype=torch.uint8, device="cuda")
+        pkg.check(L.mi_blur_planar_to_interleaved(d_p.data_ptr(), d_i.data_ptr(), w, h, c, n, None))
+        torch.cuda.synchronize()
+        assert np.array_equal(d_i.cpu().numpy(), want), (h, w, n)
+        d_back = torch.zeros_like(d_p)
+        pkg.check(L.mi_blur_interleaved_to_planar(d_i.data_ptr(), d_back.data_ptr(), w, h, c, n, None))
+        torch.cuda.synchronize()
+        assert np.array_equal(d_back.cpu().numpy(), planar), (h, w, n)
+    # unaligned pointers take the byte path
+    h, w, n = 16, 16, 2
+    planar = rng.integers(0, 256, (n, c, h, w), dtype=np.uint8)
+    buf_p = torch.zeros(planar.size + 3, dtype=torch.uint8, device="cuda")
+    buf_p[3:] = torch.from_numpy(planar.reshape(-1)).cuda()
+    buf_i = torch.zeros(planar.size + 1, dtype=torch.uint8, device="cuda")
+    pkg.check(L.mi_blur_planar_to_interleaved(buf_p.data_ptr() + 3, buf_i.data_ptr() + 1, w, h, c, n, None))
+    torch.cuda.synchronize()
+    want = np.stack([O.planar_to_interleaved(np.ascontiguousarray(planar[i])) for i in range(n)])
+    assert np.array_equal(buf_i[1:].cpu().numpy().reshape(n, h, w, c), want)
+    # argument checks
+    assert L.mi_blur_planar_to_interleaved(buf_p.data_ptr(), buf_p.data_ptr(), w, h, c, n, None) == pkg.ERR_INVALID
+    assert L.mi_blur_interleaved_to_planar(buf_p.data_ptr(), buf_i.data_ptr(), 0, h, c, n, None) == pkg.ERR_INVALID
+
+
+def test_planar_frames_blur_as_one_channel_images(pkg, L, O, torch_cuda):
+    """A planar (CImg-layout) stream needs no repack to be blurred: it is a stream of n*C one-channel images.
+    blur(planar as C=1) repacked == blur(interleaved), on the GPU end to end, 1080p 5x5 and 256x256 3x3."""
+    torch = torch_cuda
+    for (h, w, c, n, radius) in [(256, 256, 3, 6, 1), (1080, 1920, 3, 2, 2)]:
+        inter = O.lcg_stream(n, h, w, c)
+        d_i = torch.from_numpy(inter).cuda()
+        d_p = torch.empty((n, c, h, w), dtype=torch.uint8, device="cuda")
+        pkg.check(L.mi_blur_interleaved_to_planar(d_i.data_ptr(), d_p.data_ptr(), w, h, c, n, None))
+        d_pb = torch.empty_like(d_p)
+        pkg.check(L.mi_blur_enqueue(d_p.data_ptr(), d_pb.data_ptr(), w, h, 1, radius, n * c, None))      # planes as images
+        d_ib = torch.empty_like(d_i)
+        pkg.check(L.mi_blur_planar_to_interleaved(d_pb.data_ptr(), d_ib.data_ptr(), w, h, c, n, None))
+        d_direct = torch.empty_like(d_i)
+        pkg.check(L.mi_blur_enqueue(d_i.data_ptr(), d_direct.data_ptr(), w, h, c, radius, n, None))
+        torch.cuda.synchronize()
+        assert bool((d_ib == d_direct).all())
+        assert np.array_equal(d_direct[0].cpu().numpy(), O.blur(np.ascontiguousarray(inter[0]), radius))

@@ -168,3 +168,18 @@ def test_saved_reference_output_psnr(O):
     blurred = O.blur(src, 1)
     assert psnr(blurred, saved) > 45.0                        # SURVEY §4 measured 50.8 dB
     assert psnr(src, saved) < 40.0                            # and the unblurred source is far away
+
+
+def test_layout_restatement(O):
+    """Planar (CImg) <-> interleaved: the C restatement of heterogeneous_blur.c:125-134 / split_image_blur.c:40-56
+    equals the numpy transposes and round-trips; and blurring the planes one by one is blurring the interleaved image
+    (the kernel never mixes channels, gaussian_kernel.cl:44-71)."""
+    rng = np.random.default_rng(3)
+    for (c, h, w) in [(3, 5, 7), (1, 4, 4), (4, 9, 16), (2, 1, 1), (5, 3, 2)]:
+        planar = rng.integers(0, 256, (c, h, w), dtype=np.uint8)
+        inter = O.planar_to_interleaved(planar)
+        assert np.array_equal(inter, np.ascontiguousarray(planar.transpose(1, 2, 0)))
+        assert np.array_equal(O.interleaved_to_planar(inter), planar)
+        for radius in (1, 2):
+            per_plane = np.stack([O.blur(np.ascontiguousarray(planar[k][:, :, None]), radius)[:, :, 0] for k in range(c)])
+            assert np.array_equal(O.planar_to_interleaved(per_plane), O.blur(inter, radius))
