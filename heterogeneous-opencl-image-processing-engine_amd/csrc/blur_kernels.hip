@@ -37,8 +37,17 @@
 //   (blockIdx -> tile map gives each XCD a contiguous run of tiles).  Measured with
 //   rocprofv3 PMC: FETCH_SIZE*2 + WRITE_SIZE within 0.1-2.5 % of the algorithmic bytes.
 //
-// Generic kernel: one output byte per thread, any shape (pitch not a multiple of 16,
-// unaligned pointers).  Correct everywhere, fast nowhere.
+// Ragged form of the tiled kernel (RAG): pitch NOT a multiple of 16 and/or unaligned pointers
+// (1366-, 1000-, 250-pixel-wide frames).  A row is still cut into 16-byte chunks counted from the
+// ROW START, so the LDS tile and the whole compute phase are unchanged; only the edges of the pipeline
+// differ: staging uses unaligned 16-byte global loads through registers (the hardware splits them); the
+// lane that owns a row's last, partial chunk loads the 16 bytes that END at the row end instead (never
+// reading past the buffer), stores them at their row-relative LDS position and writes the right-edge clamp
+// bytes (copies of the last pixel) behind them, so no lane synthesises the right clamp; outputs are unaligned
+// 16-byte stores, the partial chunk a masked 8/4/2/1-byte store of the bytes that exist.
+//
+// Generic kernel: one output byte per thread, any shape (rows shorter than 16 bytes, more than 4
+// channels).  Correct everywhere, fast nowhere.
 #include "blur_launch.h"
 #include "../../include/mi_blur.h"
 
@@ -193,12 +202,31 @@ struct TiledParams {
     unsigned nblocks;
     int xcd;
     int debug_copy;                   // ablation only: skip the arithmetic, store the staged centre chunk
+    int tail;                         // RAG: bytes of the row's last chunk that exist (1..16); 16 otherwise
 };
+
+// 16 bytes at any address (global or LDS): the backend emits the full-width instruction and the
+// hardware (unaligned access mode) splits it where it must.
+struct __attribute__((packed, aligned(1))) Unaligned16 { u32x4 v; };
+struct __attribute__((packed, aligned(1))) Unaligned8 { u32x2 v; };
+struct __attribute__((packed, aligned(1))) Unaligned4 { uint32_t v; };
+struct __attribute__((packed, aligned(1))) Unaligned2 { uint16_t v; };
+
+// RAG output: a whole chunk as one unaligned 16-byte store, a row's partial last chunk as the 8/4/2/1-byte
+// pieces of the n (< 16) bytes that exist — the byte after them belongs to the next row.
+__device__ __forceinline__ void store_chunk_ragged(uint8_t *q, u32x4 v, int n)
+{
+    if (n >= 16) { reinterpret_cast<Unaligned16 *>(q)->v = v; return; }
+    if (n & 8) { u32x2 t; t.x = v.x; t.y = v.y; reinterpret_cast<Unaligned8 *>(q)->v = t; q += 8; v.x = v.z; v.y = v.w; }
+    if (n & 4) { reinterpret_cast<Unaligned4 *>(q)->v = v.x; q += 4; v.x = v.y; }
+    if (n & 2) { reinterpret_cast<Unaligned2 *>(q)->v = (uint16_t)v.x; q += 2; v.x >>= 16; }
+    if (n & 1) *q = (uint8_t)v.x;
+}
 
 // ----------------------------------------------------------------------------------
 // LDS-tiled vector kernel
 // ----------------------------------------------------------------------------------
-template <int C, int R, int RPG, bool DMA, bool SHFL = false>
+template <int C, int R, int RPG, bool DMA, bool SHFL = false, bool RAG = false>
 __global__ __launch_bounds__(256) void blur_tiled_kernel(const TiledParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -241,7 +269,31 @@ __global__ __launch_bounds__(256) void blur_tiled_kernel(const TiledParams p)
             if (act && row < nrows) {
                 const int sr = min(max(ty0 - R + row, 0), p.H - 1);
                 const uint8_t *g = img_in + ((unsigned)sr * (unsigned)p.pitch + col_off);
-                if constexpr (DMA) {
+                if constexpr (RAG) {
+                    const uint8_t *rowp = img_in + (size_t)sr * (size_t)p.pitch;
+                    uint8_t *dst = lds + (size_t)(u * rpi * cpr2 + lane) * 16u;
+                    if (x0c + cc - 1 == p.cpr - 1) {
+                        // the row's last chunk: the 16 bytes that END at the row end, at their row-relative place;
+                        // behind them the right-edge clamp (byte pitch+k = byte pitch-C+(k mod C): copies of the
+                        // last pixel, all taken from the last dword), as far as any window reaches: the rest of
+                        // this chunk, plus 8 bytes of the right halo chunk when this lane is a column of the strip
+                        const u32x4 v = reinterpret_cast<const Unaligned16 *>(rowp + p.pitch - 16)->v;
+                        reinterpret_cast<Unaligned16 *>(dst - (16 - p.tail))->v = v;
+                        const int len = (16 - p.tail) + (cc == cpr2 - 1 ? 0 : 8);
+                        uint8_t *pd = dst + p.tail;
+                        const uint32_t fill[6] = {__builtin_amdgcn_perm(0u, v.w, sel_right(C, 0)), __builtin_amdgcn_perm(0u, v.w, sel_right(C, 1)),
+                                                  __builtin_amdgcn_perm(0u, v.w, sel_right(C, 2)), __builtin_amdgcn_perm(0u, v.w, sel_right(C, 3)),
+                                                  __builtin_amdgcn_perm(0u, v.w, sel_right(C, 4)), __builtin_amdgcn_perm(0u, v.w, sel_right(C, 5))};
+#pragma unroll
+                        for (int q = 0; q < 6; q++) {
+                            if (4 * q + 4 <= len) reinterpret_cast<Unaligned4 *>(pd + 4 * q)->v = fill[q];
+                            else if (4 * q < len)      // the last 1-3 bytes one by one: nothing is written past `len`
+                                for (int b = 0; b < len - 4 * q; b++) pd[4 * q + b] = (uint8_t)(fill[q] >> (8 * b));
+                        }
+                    } else {
+                        *reinterpret_cast<u32x4 *>(dst) = reinterpret_cast<const Unaligned16 *>(rowp + col_off)->v;
+                    }
+                } else if constexpr (DMA) {
                     uint8_t *base = lds + (size_t)(u * rpi * cpr2) * 16u;    // wave-uniform; + lane*16 by HW
                     __builtin_amdgcn_global_load_lds(
                         (const void __attribute__((address_space(1))) *)g,
@@ -261,7 +313,7 @@ __global__ __launch_bounds__(256) void blur_tiled_kernel(const TiledParams p)
     const int r0 = grp * RPG;
     if (grp >= p.ngroups || r0 >= rows_out) return;   // no barrier below
     const bool at_start = (x0c + col) == 0;
-    const bool at_end = (x0c + col) == p.cpr - 1;
+    const bool at_end = !RAG && (x0c + col) == p.cpr - 1;      // RAG: the right clamp bytes are in LDS already
     const bool any_edge = __builtin_amdgcn_ballot_w64(at_start || at_end) != 0ull;
     const int lrow = cpr2 * 16;
     const uint8_t *lp = lds + ((size_t)r0 * cpr2 + (col + 1)) * 16u;
@@ -273,7 +325,8 @@ __global__ __launch_bounds__(256) void blur_tiled_kernel(const TiledParams p)
         for (int r = 0; r < RPG; r++)
             if (r0 + r < rows_out) {
                 const u32x4 v = *reinterpret_cast<const u32x4 *>(lp + (r + R) * lrow);
-                *reinterpret_cast<u32x4 *>(op + (size_t)r * (size_t)p.pitch) = v;
+                if constexpr (RAG) store_chunk_ragged(op + (size_t)r * (size_t)p.pitch, v, (x0c + col) == p.cpr - 1 ? p.tail : 16);
+                else *reinterpret_cast<u32x4 *>(op + (size_t)r * (size_t)p.pitch) = v;
             }
         return;
     }
@@ -311,7 +364,8 @@ __global__ __launch_bounds__(256) void blur_tiled_kernel(const TiledParams p)
         }
         if (r0 + r < rows_out) {
             u32x4 v; v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
-            *reinterpret_cast<u32x4 *>(op + (size_t)r * (size_t)p.pitch) = v;
+            if constexpr (RAG) store_chunk_ragged(op + (size_t)r * (size_t)p.pitch, v, (x0c + col) == p.cpr - 1 ? p.tail : 16);
+            else *reinterpret_cast<u32x4 *>(op + (size_t)r * (size_t)p.pitch) = v;
         }
     }
 }
@@ -514,13 +568,19 @@ __global__ __launch_bounds__(256) void blur_generic_kernel(const GenericParams p
 Tunables &tunables()
 {
     static Tunables t = [] {
-        Tunables v{1, 0, 1, 0, 0, 0, 0, 1};  // rpg 0 / stream_bh 0 = choose per launch
+        Tunables v{1, 0, 1, 0, 0, 0, 0, 1, 1};  // rpg 0 / stream_bh 0 = choose per launch
         if (const char *e = getenv("MI_BLUR_STAGE")) v.stage_dma = strcmp(e, "reg") != 0;
         if (const char *e = getenv("MI_BLUR_RPG")) { const int r = atoi(e); v.rpg = (r == 4 || r == 8 || r == 16) ? r : 0; }
         if (const char *e = getenv("MI_BLUR_XCD")) v.xcd_remap = atoi(e) != 0;
         return v;
     }();
     return t;
+}
+
+// The ragged form of the tiled kernel: any pitch of at least one chunk, any pointer alignment.
+static bool ragged_eligible(int width, int channels)
+{
+    return channels >= 1 && channels <= 4 && (long long)width * channels >= 16;
 }
 
 bool tiled_eligible(const void *in, const void *out, int width, int channels)
@@ -544,8 +604,11 @@ static int do_launch(K kernel, dim3 grid, dim3 block, size_t lds, const LaunchDe
 
 template <int C, int R>
 static int launch_tiled_cr(const LaunchDesc &d, const TiledParams &p, dim3 grid, dim3 block, size_t lds,
-                           int rpg, bool dma)
+                           int rpg, bool dma, bool ragged)
 {
+    if (ragged)
+        return rpg == 4 ? do_launch(blur_tiled_kernel<C, R, 4, false, false, true>, grid, block, lds, d, p)
+                        : do_launch(blur_tiled_kernel<C, R, 8, false, false, true>, grid, block, lds, d, p);
     if (tunables().row_shuffle && dma) {
         if (rpg == 16) return do_launch(blur_tiled_kernel<C, R, 16, true, true>, grid, block, lds, d, p);
         if (rpg == 4) return do_launch(blur_tiled_kernel<C, R, 4, true, true>, grid, block, lds, d, p);
@@ -563,22 +626,22 @@ static int launch_tiled_cr(const LaunchDesc &d, const TiledParams &p, dim3 grid,
 
 template <int R>
 static int launch_tiled_r(const LaunchDesc &d, const TiledParams &p, dim3 grid, dim3 block, size_t lds,
-                          int rpg, bool dma)
+                          int rpg, bool dma, bool ragged)
 {
     switch (d.channels) {
-    case 1: return launch_tiled_cr<1, R>(d, p, grid, block, lds, rpg, dma);
-    case 2: return launch_tiled_cr<2, R>(d, p, grid, block, lds, rpg, dma);
-    case 3: return launch_tiled_cr<3, R>(d, p, grid, block, lds, rpg, dma);
-    case 4: return launch_tiled_cr<4, R>(d, p, grid, block, lds, rpg, dma);
+    case 1: return launch_tiled_cr<1, R>(d, p, grid, block, lds, rpg, dma, ragged);
+    case 2: return launch_tiled_cr<2, R>(d, p, grid, block, lds, rpg, dma, ragged);
+    case 3: return launch_tiled_cr<3, R>(d, p, grid, block, lds, rpg, dma, ragged);
+    case 4: return launch_tiled_cr<4, R>(d, p, grid, block, lds, rpg, dma, ragged);
     }
     return MI_BLUR_ERR_INVALID;
 }
 
-static int launch_tiled(const LaunchDesc &d)
+static int launch_tiled(const LaunchDesc &d, bool ragged = false)
 {
     const Tunables &tun = tunables();
     const int R = d.radius;
-    const int pitch = d.width * d.channels, cpr = pitch / 16, rows = d.y1 - d.y0;
+    const int pitch = d.width * d.channels, cpr = (pitch + 15) / 16, rows = d.y1 - d.y0;   // ragged: last chunk partial
     // Output rows per thread.  8 amortises the 2R priming rows of the sliding window best when the grid is
     // large; small and mid-size grids (a batch of 35 256x256 images is ~840 waves at 8 rows) finish sooner
     // with 4 — more, shorter waves per CU (measured: 6.2 vs 7.4 us at batch 35, equal by ~20k waves).
@@ -587,6 +650,7 @@ static int launch_tiled(const LaunchDesc &d)
         const long long waves8 = (long long)d.n_images * rows * cpr / (8 * 64);
         rpg = waves8 < 16384 ? 4 : 8;
     }
+    if (ragged && rpg == 16) rpg = 8;
 
     TiledParams p{};
     p.in = d.in; p.out = d.out;
@@ -616,11 +680,12 @@ static int launch_tiled(const LaunchDesc &d)
     p.nblocks = (unsigned)nblocks;
     p.xcd = tun.xcd_remap && nblocks >= 16;
     p.debug_copy = tun.debug_copy;
+    p.tail = pitch % 16 ? pitch % 16 : 16;
 
     const dim3 grid((unsigned)nblocks), block((unsigned)((p.ncols * p.ngroups + 63) / 64 * 64));
     const size_t lds = (size_t)(p.TH + 2 * R) * (p.ncols + 2) * 16;
-    return R == 1 ? launch_tiled_r<1>(d, p, grid, block, lds, rpg, tun.stage_dma != 0)
-                  : launch_tiled_r<2>(d, p, grid, block, lds, rpg, tun.stage_dma != 0);
+    return R == 1 ? launch_tiled_r<1>(d, p, grid, block, lds, rpg, tun.stage_dma != 0, ragged)
+                  : launch_tiled_r<2>(d, p, grid, block, lds, rpg, tun.stage_dma != 0, ragged);
 }
 
 static int launch_stream(const LaunchDesc &d)
@@ -697,12 +762,13 @@ int launch(const LaunchDesc &d)
         if (d.variant != MI_BLUR_VARIANT_AUTO && d.variant != MI_BLUR_VARIANT_TILED) return MI_BLUR_ERR_UNSUPPORTED;
         return launch_tiled(d);
     }
+    const bool can_rag = ragged_eligible(d.width, d.channels) && tunables().ragged;
     switch (d.variant) {
     case MI_BLUR_VARIANT_AUTO:
-        if (!can_tile) return launch_generic(d);
+        if (!can_tile) return can_rag ? launch_tiled(d, true) : launch_generic(d);
         return tunables().prefer_stream ? launch_stream(d) : launch_tiled(d);
     case MI_BLUR_VARIANT_GENERIC: return launch_generic(d);
-    case MI_BLUR_VARIANT_TILED: return can_tile ? launch_tiled(d) : MI_BLUR_ERR_INVALID;
+    case MI_BLUR_VARIANT_TILED: return can_tile ? launch_tiled(d) : can_rag ? launch_tiled(d, true) : MI_BLUR_ERR_INVALID;
     case MI_BLUR_VARIANT_STREAM: return can_tile ? launch_stream(d) : MI_BLUR_ERR_INVALID;
     }
     return MI_BLUR_ERR_INVALID;

@@ -31,7 +31,7 @@ bool tiled_eligible(const void *in, const void *out, int width, int channels);
 
 // Tunables: defaults from env (MI_BLUR_STAGE=dma|reg, MI_BLUR_RPG=8|16, MI_BLUR_XCD=0|1),
 // changeable at run time through mi_blur_set_option.
-struct Tunables { int stage_dma; int rpg; int xcd_remap; int debug_copy; int row_shuffle; int prefer_stream; int stream_bh; int zero_copy; };
+struct Tunables { int stage_dma; int rpg; int xcd_remap; int debug_copy; int row_shuffle; int prefer_stream; int stream_bh; int zero_copy; int ragged; };
 Tunables &tunables();
 
 }  // namespace mi_blur

@@ -85,6 +85,7 @@ extern "C" int mi_blur_set_option(const char *key, int value)
     else if (!strcmp(key, "row_shuffle")) t.row_shuffle = value != 0;
     else if (!strcmp(key, "prefer_stream")) t.prefer_stream = value != 0;
     else if (!strcmp(key, "zero_copy")) t.zero_copy = value != 0;
+    else if (!strcmp(key, "ragged_tiled")) t.ragged = value != 0;
     else if (!strcmp(key, "stream_band_rows")) { if (value < 0 || value > 4096) return MI_BLUR_ERR_INVALID; t.stream_bh = value; }
     else return MI_BLUR_ERR_INVALID;
     return MI_BLUR_OK;

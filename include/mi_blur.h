@@ -53,7 +53,7 @@ typedef enum mi_blur_status {
 typedef enum mi_blur_variant {
     MI_BLUR_VARIANT_AUTO = 0,        /* LDS-tiled vector kernel when pitch%16==0 && channels<=4, else generic */
     MI_BLUR_VARIANT_GENERIC = 1,     /* one output byte per thread, any shape */
-    MI_BLUR_VARIANT_TILED = 2,       /* LDS halo tile + 16-B vector loads (fails with _INVALID if ineligible) */
+    MI_BLUR_VARIANT_TILED = 2,       /* LDS halo tile + 16-B vector loads (ragged form for odd pitches; _INVALID if C > 4 or rows < 16 B) */
     MI_BLUR_VARIANT_STREAM = 3       /* barrier-free register sliding window + DPP row pass (same eligibility) */
 } mi_blur_variant;
 
@@ -67,6 +67,8 @@ int mi_blur_version(void);
  *   "row_shuffle"      1 = x-neighbour bytes by DPP wave shifts (LDS only at wave/tile edges), 0 = from LDS (default)
  *   "prefer_stream"    1 = AUTO picks the streaming variant instead of the tiled one (default 0)
  *   "stream_band_rows" streaming variant: output rows per wave (0 = chosen per launch)
+ *   "ragged_tiled"     1 (default) = rows that are not a multiple of 16 bytes / unaligned pointers take the ragged form of the
+ *                      tiled kernel; 0 = they take the generic one-byte-per-thread kernel
  *   "zero_copy"        1 (default) = submits whose input AND output are pinned host memory run the kernel on the
  *                      caller's buffers in place (no staging copies); 0 = always H2D -> kernel -> D2H */
 int mi_blur_set_option(const char *key, int value);

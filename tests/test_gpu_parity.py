@@ -45,6 +45,7 @@ def reset_opts(L):
     L.mi_blur_set_option(b"stream_band_rows", 0)
     L.mi_blur_set_option(b"stage_dma", 1)
     L.mi_blur_set_option(b"zero_copy", 1)
+    L.mi_blur_set_option(b"ragged_tiled", 1)
     L.mi_blur_set_option(b"rows_per_thread", 0)
     L.mi_blur_set_option(b"xcd_remap", 1)
 
@@ -154,12 +155,16 @@ def test_auto_dispatch_and_ineligible_tiled(pkg, L, O, torch_cuda):
     assert np.array_equal(gpu_blur(pkg, L, torch_cuda, host, 1, pkg.VARIANT_AUTO), want_batch(O, host, 1))
     d = torch_cuda.zeros(2 * 33 * 17 * 3, dtype=torch_cuda.uint8, device="cuda")
     o = torch_cuda.zeros_like(d)
-    assert L.mi_blur_enqueue_ex(d.data_ptr(), o.data_ptr(), 17, 33, 3, 1, 2, 0, 33, pkg.VARIANT_TILED, None) == pkg.ERR_INVALID
+    # pitch 51 takes the ragged form of the tiled kernel; rows shorter than one chunk (pitch 15) or C = 5 cannot
+    assert L.mi_blur_enqueue_ex(d.data_ptr(), o.data_ptr(), 17, 33, 3, 1, 2, 0, 33, pkg.VARIANT_TILED, None) == pkg.OK
+    assert L.mi_blur_enqueue_ex(d.data_ptr(), o.data_ptr(), 5, 33, 3, 1, 2, 0, 33, pkg.VARIANT_TILED, None) == pkg.ERR_INVALID
+    assert L.mi_blur_enqueue_ex(d.data_ptr(), o.data_ptr(), 17, 19, 5, 1, 2, 0, 19, pkg.VARIANT_TILED, None) == pkg.ERR_INVALID
+    assert L.mi_blur_enqueue_ex(d.data_ptr(), o.data_ptr(), 17, 33, 3, 1, 2, 0, 33, pkg.VARIANT_STREAM, None) == pkg.ERR_INVALID
     assert L.mi_blur_enqueue_ex(d.data_ptr(), d.data_ptr(), 17, 33, 3, 1, 2, 0, 33, 0, None) == pkg.ERR_INVALID
     assert L.mi_blur_enqueue_ex(d.data_ptr(), o.data_ptr(), 17, 33, 3, 3, 2, 0, 33, 0, None) == pkg.ERR_INVALID
     assert L.mi_blur_enqueue_ex(d.data_ptr(), o.data_ptr(), 17, 33, 3, 1, 2, 5, 5, 0, None) == pkg.ERR_INVALID
     assert L.mi_blur_enqueue_ex(d.data_ptr(), o.data_ptr(), 17, 33, 3, 1, 0, 0, 33, 0, None) == pkg.OK     # empty batch
-    # misaligned device pointers fall back to the generic kernel under AUTO
+    # misaligned device pointers take the ragged form under AUTO
     host = O.lcg_stream(1, 16, 16, 3)
     buf = torch_cuda.zeros(host.size + 64, dtype=torch_cuda.uint8, device="cuda")
     out = torch_cuda.zeros(host.size + 64, dtype=torch_cuda.uint8, device="cuda")
@@ -167,6 +172,46 @@ def test_auto_dispatch_and_ineligible_tiled(pkg, L, O, torch_cuda):
     pkg.check(L.mi_blur_enqueue(buf.data_ptr() + 3, out.data_ptr() + 5, 16, 16, 3, 1, 1, None))
     torch_cuda.cuda.synchronize()
     assert np.array_equal(out[5:5 + host.size].cpu().numpy().reshape(host.shape), want_batch(O, host, 1))
+
+
+RAGGED_SHAPES = [(33, 17, 3), (5, 16, 1), (1, 17, 1), (2, 6, 3), (31, 29, 4), (40, 250, 3), (64, 1366, 3), (19, 1000, 3),
+                 (9, 9, 2), (300, 33, 1), (7, 2731, 3), (50, 37, 2), (3, 21, 1), (12, 4099, 1), (65, 170, 3)]
+
+
+@pytest.mark.parametrize("h,w,c", RAGGED_SHAPES)
+@pytest.mark.parametrize("radius", [1, 2])
+def test_ragged_tiled_bit_exact(pkg, L, O, torch_cuda, h, w, c, radius):
+    """Rows that are not a multiple of 16 bytes: the ragged form of the tiled kernel == oracle == generic kernel, for
+    batches, for every rows-per-thread setting, at odd pointer offsets, as bands; gpu_blur's guard bytes catch a store
+    that spills over the end (the partial last chunk must write only the bytes that exist)."""
+    n = 3
+    try:
+        for host in adversarial(O, h, w, c, n, h * 13 + w):
+            want = want_batch(O, host, radius)
+            for opts in ({"rows_per_thread": 0}, {"rows_per_thread": 4}, {"rows_per_thread": 8, "xcd_remap": 0}, {"rows_per_thread": 16}):
+                got = gpu_blur(pkg, L, torch_cuda, host, radius, pkg.VARIANT_TILED, opts=opts)
+                assert np.array_equal(got, want), f"{(got != want).sum()} bytes differ, opts={opts}"
+        host = O.lcg_stream(n, h, w, c)
+        want = want_batch(O, host, radius)
+        assert np.array_equal(gpu_blur(pkg, L, torch_cuda, host, radius, pkg.VARIANT_AUTO, opts={"ragged_tiled": 0}), want)   # generic
+        pkg.check(L.mi_blur_set_option(b"ragged_tiled", 1))
+        if h >= 3:
+            y0, y1 = 1, h - 1
+            got = gpu_blur(pkg, L, torch_cuda, host, radius, pkg.VARIANT_TILED, y0=y0, y1=y1)
+            assert np.array_equal(got, want[:, y0:y1])
+        # odd pointer offsets (input +1, output +7)
+        torch = torch_cuda
+        buf = torch.full((host.size + 64,), 0xA5, dtype=torch.uint8, device="cuda")
+        out = torch.full((host.size + 64,), 0x5A, dtype=torch.uint8, device="cuda")
+        buf[1:1 + host.size] = torch.from_numpy(host.reshape(-1)).cuda()
+        pkg.check(L.mi_blur_enqueue_ex(buf.data_ptr() + 1, out.data_ptr() + 7, w, h, c, radius, n, 0, h, pkg.VARIANT_TILED, None))
+        torch.cuda.synchronize()
+        o = out.cpu().numpy()
+        assert np.array_equal(o[7:7 + host.size].reshape(host.shape), want)
+        assert (o[:7] == 0x5A).all() and (o[7 + host.size:] == 0x5A).all(), "wrote outside the output"
+    finally:
+        reset_opts(L)
+        L.mi_blur_set_option(b"ragged_tiled", 1)
 
 
 def test_golden_hashes_on_gpu(pkg, L, O, torch_cuda, golden):
