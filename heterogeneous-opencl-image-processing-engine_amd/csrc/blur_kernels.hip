@@ -40,9 +40,9 @@
 // Ragged form of the tiled kernel (RAG): pitch NOT a multiple of 16 and/or unaligned pointers
 // (1366-, 1000-, 250-pixel-wide frames).  A row is still cut into 16-byte chunks counted from the
 // ROW START, so the LDS tile and the whole compute phase are unchanged; only the edges of the pipeline
-// differ: staging uses unaligned 16-byte global loads through registers (the hardware splits them); the
-// lane that owns a row's last, partial chunk loads the 16 bytes that END at the row end instead (never
-// reading past the buffer), stores them at their row-relative LDS position and writes the right-edge clamp
+// differ: staging gives LDS-DMA the unaligned global address as it is (the hardware splits the fetch); the
+// lane that owns a row's last, partial chunk loads — through registers — the 16 bytes that END at the row end
+// (never reading past the buffer), stores them at their row-relative LDS position and writes the right-edge clamp
 // bytes (copies of the last pixel) behind them, so no lane synthesises the right clamp; outputs are unaligned
 // 16-byte stores, the partial chunk a masked 8/4/2/1-byte store of the bytes that exist.
 //
@@ -290,6 +290,12 @@ __global__ __launch_bounds__(256) void blur_tiled_kernel(const TiledParams p)
                             else if (4 * q < len)      // the last 1-3 bytes one by one: nothing is written past `len`
                                 for (int b = 0; b < len - 4 * q; b++) pd[4 * q + b] = (uint8_t)(fill[q] >> (8 * b));
                         }
+                    } else if constexpr (DMA) {
+                        // LDS-DMA takes the unaligned global address as it is; the LDS side stays lane-ordered
+                        uint8_t *base = lds + (size_t)(u * rpi * cpr2) * 16u;
+                        __builtin_amdgcn_global_load_lds(
+                            (const void __attribute__((address_space(1))) *)(rowp + col_off),
+                            (void __attribute__((address_space(3))) *)base, 16, 0, 0);
                     } else {
                         *reinterpret_cast<u32x4 *>(dst) = reinterpret_cast<const Unaligned16 *>(rowp + col_off)->v;
                     }
@@ -606,9 +612,13 @@ template <int C, int R>
 static int launch_tiled_cr(const LaunchDesc &d, const TiledParams &p, dim3 grid, dim3 block, size_t lds,
                            int rpg, bool dma, bool ragged)
 {
-    if (ragged)
+    if (ragged) {
+        if (dma)
+            return rpg == 4 ? do_launch(blur_tiled_kernel<C, R, 4, true, false, true>, grid, block, lds, d, p)
+                            : do_launch(blur_tiled_kernel<C, R, 8, true, false, true>, grid, block, lds, d, p);
         return rpg == 4 ? do_launch(blur_tiled_kernel<C, R, 4, false, false, true>, grid, block, lds, d, p)
                         : do_launch(blur_tiled_kernel<C, R, 8, false, false, true>, grid, block, lds, d, p);
+    }
     if (tunables().row_shuffle && dma) {
         if (rpg == 16) return do_launch(blur_tiled_kernel<C, R, 16, true, true>, grid, block, lds, d, p);
         if (rpg == 4) return do_launch(blur_tiled_kernel<C, R, 4, true, true>, grid, block, lds, d, p);

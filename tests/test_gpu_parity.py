@@ -188,7 +188,8 @@ def test_ragged_tiled_bit_exact(pkg, L, O, torch_cuda, h, w, c, radius):
     try:
         for host in adversarial(O, h, w, c, n, h * 13 + w):
             want = want_batch(O, host, radius)
-            for opts in ({"rows_per_thread": 0}, {"rows_per_thread": 4}, {"rows_per_thread": 8, "xcd_remap": 0}, {"rows_per_thread": 16}):
+            for opts in ({"rows_per_thread": 0, "stage_dma": 1}, {"rows_per_thread": 4, "stage_dma": 0},
+                         {"rows_per_thread": 8, "xcd_remap": 0, "stage_dma": 1}, {"rows_per_thread": 16, "stage_dma": 0}):
                 got = gpu_blur(pkg, L, torch_cuda, host, radius, pkg.VARIANT_TILED, opts=opts)
                 assert np.array_equal(got, want), f"{(got != want).sum()} bytes differ, opts={opts}"
         host = O.lcg_stream(n, h, w, c)
