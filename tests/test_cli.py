@@ -224,3 +224,23 @@ def test_resident_row_shards_on_virtual_gpus(apps, O, tmp_path):
             for _ in range(passes):
                 want = O.blur(want, radius)
             assert np.array_equal(read_ppm(tmp_path / fname), want), (ksize, extra)
+
+
+@pytest.mark.gpu
+def test_hosts_with_ragged_frame_sizes(apps, O, tmp_path):
+    """Frames whose rows are not a multiple of 16 bytes (250x167x3: pitch 750) through both hosts: zero-copy A1 batches take
+    the ragged form of the tiled kernel, A2's strided bands take the staged path; pixels must equal the oracle."""
+    het, spl = apps
+    img = O.lcg_image(167, 250, 3)
+    write_ppm(tmp_path / "in.ppm", img)
+    for ksize, radius in (("3", 1), ("5", 2)):
+        want = O.blur(img, radius)
+        r = run([het, "gpu", "1.0", "35", "--image", "in.ppm", "--images", "300", "--ksize", ksize, "--save", "g.ppm"], tmp_path)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert np.array_equal(read_ppm(tmp_path / "g.ppm"), want)
+        r = run([het, "both", "0.6", "35", "--image", "in.ppm", "--images", "300", "--ksize", ksize, "--save", "b.ppm"], tmp_path)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert np.array_equal(read_ppm(tmp_path / "b.ppm"), want)
+        r = run([spl, "0.7", "16", "--image", "in.ppm", "--images", "96", "--ksize", ksize, "--save", "s.ppm"], tmp_path)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert np.array_equal(read_ppm(tmp_path / "s.ppm"), want)
