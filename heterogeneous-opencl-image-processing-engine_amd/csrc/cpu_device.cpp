@@ -178,6 +178,22 @@ void fill_synthetic(uint8_t *host, int W, int H, int C, int first_index, int n_i
     Pool::get().run(std::min(n_threads, n_images), [&](int) { worker(); });
 }
 
+// n blocks of `bytes` bytes from src (stride src_stride) to dst (stride dst_stride), split over a few pool threads when
+// there is enough to move: the staging copies of a GPU context fed from pageable caller memory.
+void copy_blocks(uint8_t *dst, size_t dst_stride, const uint8_t *src, size_t src_stride, size_t bytes, int n, int n_threads)
+{
+    const size_t total = bytes * (size_t)n;
+    if (n_threads <= 1 || total < (1u << 20)) {
+        for (int i = 0; i < n; i++) memcpy(dst + (size_t)i * dst_stride, src + (size_t)i * src_stride, bytes);
+        return;
+    }
+    // cut every block into n_threads slices so the split is even whatever n is
+    Pool::get().run(n_threads, [&](int t) {
+        const size_t b = bytes * (size_t)t / (size_t)n_threads, e = bytes * (size_t)(t + 1) / (size_t)n_threads;
+        for (int i = 0; i < n; i++) memcpy(dst + (size_t)i * dst_stride + b, src + (size_t)i * src_stride + b, e - b);
+    });
+}
+
 uint64_t fnv1a64(const uint8_t *p, size_t n)
 {
     uint64_t h = 0xcbf29ce484222325ull;
