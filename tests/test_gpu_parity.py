@@ -638,3 +638,28 @@ def test_planar_frames_blur_as_one_channel_images(pkg, L, O, torch_cuda):
         torch.cuda.synchronize()
         assert bool((d_ib == d_direct).all())
         assert np.array_equal(d_direct[0].cpu().numpy(), O.blur(np.ascontiguousarray(inter[0]), radius))
+
+
+@pytest.mark.parametrize("W,H", [(26752, 26757), (26750, 26759)])
+def test_single_image_near_the_2gib_limit(pkg, L, O, torch_cuda, W, H):
+    """The largest frame the interface takes is just under 2^31 bytes (32-bit offsets inside an image, like the
+    reference's `int idx`): 26752 x 26757 x 3 (aligned rows) and 26750 x 26759 x 3 (ragged rows, pitch 80250), both
+    within 75 kB of the limit.  Sampled row bands (top, around the 2^30-byte offset, middle, bottom) of the output equal
+    the oracle on the same rows; one more row is refused."""
+    torch = torch_cuda
+    c = 3
+    assert W * H * c < 2**31 <= W * (H + 1) * c
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    d_in = torch.randint(0, 256, (H, W, c), dtype=torch.uint8, device="cuda", generator=g)
+    d_out = torch.empty_like(d_in)
+    for radius in (1, 2):
+        pkg.check(L.mi_blur_enqueue_ex(d_in.data_ptr(), d_out.data_ptr(), W, H, c, radius, 1, 0, H, pkg.VARIANT_TILED, None))
+        torch.cuda.synchronize()
+        for r0 in (0, 13376, H // 2 + 5, H - 8):         # 13380 rows * ~80 kB is just past 2^30
+            lo, hi = max(r0 - radius, 0), min(r0 + 8 + radius, H)
+            band = np.ascontiguousarray(d_in[lo:hi].cpu().numpy())
+            ref = O.blur(band, radius)                     # exact for rows whose window lies inside the band; where the
+            a = r0 - lo                                    # band touches the image edge the clamp is the image's own
+            assert np.array_equal(d_out[r0:r0 + 8].cpu().numpy(), ref[a:a + 8]), (radius, r0)
+    d_big = torch.empty(8, dtype=torch.uint8, device="cuda")   # never touched: the call must be refused up front
+    assert L.mi_blur_enqueue_ex(d_big.data_ptr(), d_out.data_ptr(), W, H + 1, c, 1, 1, 0, H + 1, 0, None) == pkg.ERR_INVALID
