@@ -12,8 +12,9 @@ def main():
     import torch  # noqa: F401
     pkg = entry.load_package()
     L = pkg.lib()
-    for name, (h, w, c, r, pool) in {"hd5": (1080, 1920, 3, 2, 64), "hd3": (1080, 1920, 3, 1, 64),
-                                     "a1one": (256, 256, 3, 1, 5000)}.items():
+    shapes = {"hd5": (1080, 1920, 3, 2, 64), "hd3": (1080, 1920, 3, 1, 64), "a1one": (256, 256, 3, 1, 5000)}
+    want = sys.argv[1].split(",") if len(sys.argv) > 1 else list(shapes)
+    for name, (h, w, c, r, pool) in ((k, shapes[k]) for k in want):
         ctx = pkg.Context(0, w, h, c, r, max_batch=1, n_slots=1)
         ctx.resident_alloc(pool)
         ctx.resident_fill_synthetic(0)
