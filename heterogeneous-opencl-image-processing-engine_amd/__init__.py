@@ -137,6 +137,8 @@ def lib() -> C.CDLL:
         "mi_blur_sync": (i, [vp, C.POINTER(Timing)]),
         "mi_blur_reset_timing": (None, [vp]),
         "mi_blur_get_timing": (C.c_int, [vp, C.c_void_p]),
+        "mi_blur_resident_run_fused": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
+        "mi_blur_resident_batches_done": (C.c_int, [vp]),
         "mi_blur_zero_copy_launches": (C.c_uint64, [vp]),
         "mi_blur_resident_alloc": (i, [vp, i]),
         "mi_blur_resident_fill_synthetic": (i, [vp, i]),
@@ -262,6 +264,12 @@ class Context:
     def resident_run(self, n_images: int, batch: int, timed: int | bool = 0) -> None:
         """timed: 0/False none, 1/True every launch, n every n-th launch carries timestamp events."""
         check(lib().mi_blur_resident_run(self.h, n_images, batch, int(timed)), "mi_blur_resident_run")
+
+    def resident_run_fused(self, n_images: int, batch: int, timed: bool = False) -> None:
+        check(lib().mi_blur_resident_run_fused(self.h, n_images, batch, 1 if timed else 0), "mi_blur_resident_run_fused")
+
+    def resident_batches_done(self) -> int:
+        return int(lib().mi_blur_resident_batches_done(self.h))
 
     def timed_coverage(self) -> tuple[int, int]:
         n, b = C.c_uint64(), C.c_uint64()

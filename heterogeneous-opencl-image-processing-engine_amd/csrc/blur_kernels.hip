@@ -226,19 +226,30 @@ __device__ __forceinline__ void store_chunk_ragged(uint8_t *q, u32x4 v, int n)
 // ----------------------------------------------------------------------------------
 // LDS-tiled vector kernel
 // ----------------------------------------------------------------------------------
-template <int C, int R, int RPG, bool DMA, bool SHFL = false, bool RAG = false>
-__global__ __launch_bounds__(256) void blur_tiled_kernel(const TiledParams p)
+// blockIdx -> tile.  Blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous run of the
+// n tiles so tile-edge halo rows are L2 hits.  A bijection of [0, n).  Speed only.
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned L, unsigned n)
+{
+    const unsigned q = n >> 3, r = n & 7u, x = L & 7u, k = L >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+// 16-byte output store that writes through the (per-XCD, mutually non-coherent) L2 to memory: when its vmcnt has
+// drained the bytes are visible device-wide without an L2 write-back fence.  Fused stream only.
+__device__ __forceinline__ void store16_write_through(uint8_t *q, u32x4 v)
+{
+    // s_nop: a store of more than 8 bytes needs two wait states before a VALU may overwrite its data registers; the
+    // compiler's hazard pass does not look inside inline asm
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(q), "v"(v) : "memory");
+}
+
+// One workgroup's tile (tile number L of the launch).  Threads may return early; the only barrier is after staging.
+// WT: outputs are written through L2 (store16_write_through).
+template <int C, int R, int RPG, bool DMA, bool SHFL, bool RAG, bool WT = false>
+__device__ __forceinline__ void tiled_tile(const TiledParams &p, unsigned L)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int t = threadIdx.x, NT = blockDim.x;
-
-    // blockIdx -> tile.  Blocks b and b+8 share an XCD (round-robin dispatch); give each
-    // XCD a contiguous run of tiles so tile-edge halo rows are L2 hits.  Speed only.
-    unsigned L = blockIdx.x;
-    if (p.xcd) {
-        const unsigned n = p.nblocks, q = n >> 3, r = n & 7u, x = L & 7u, k = L >> 3;
-        L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
-    }
     const int strip = (int)(L % (unsigned)p.nstrips);
     const unsigned t2 = L / (unsigned)p.nstrips;
     const int ty = (int)(t2 % (unsigned)p.ntiles_y);
@@ -371,8 +382,44 @@ __global__ __launch_bounds__(256) void blur_tiled_kernel(const TiledParams p)
         if (r0 + r < rows_out) {
             u32x4 v; v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
             if constexpr (RAG) store_chunk_ragged(op + (size_t)r * (size_t)p.pitch, v, (x0c + col) == p.cpr - 1 ? p.tail : 16);
+            else if constexpr (WT) store16_write_through(op + (size_t)r * (size_t)p.pitch, v);
             else *reinterpret_cast<u32x4 *>(op + (size_t)r * (size_t)p.pitch) = v;
         }
+    }
+}
+
+template <int C, int R, int RPG, bool DMA, bool SHFL = false, bool RAG = false>
+__global__ __launch_bounds__(256) void blur_tiled_kernel(const TiledParams p)
+{
+    tiled_tile<C, R, RPG, DMA, SHFL, RAG>(p, p.xcd ? xcd_contiguous(blockIdx.x, p.nblocks) : blockIdx.x);
+}
+
+// Fused stream: ONE dispatch for a whole pass of the resident stream, with the batch kept as the unit of completion.
+// Blocks are ordered batch by batch (XCD-contiguous inside a batch's window of tiles); the last block of a batch to
+// finish raises that batch's flag in host-visible memory, so a consumer sees batches complete in stream order while
+// the GPU never pays a per-batch dispatch (4 us floor + ~3.5 us of dispatch processing each).
+struct FusedParams {
+    unsigned *count;          // device, one counter per batch, zeroed before the launch
+    unsigned *flag;           // host-visible (pinned), one word per batch: set to `epoch` when the batch is complete
+    unsigned tiles_per_batch; // batch_images * tiles per image
+    unsigned epoch;
+};
+
+template <int C, int R, int RPG>
+__global__ __launch_bounds__(256) void blur_fused_kernel(const TiledParams p, const FusedParams f)
+{
+    const unsigned b = blockIdx.x / f.tiles_per_batch, base = b * f.tiles_per_batch;
+    const unsigned nb = min(f.tiles_per_batch, p.nblocks - base);          // the last batch may be short
+    const unsigned w = blockIdx.x - base;
+    tiled_tile<C, R, RPG, true, false, false, true>(p, base + (p.xcd && nb >= 16 ? xcd_contiguous(w, nb) : w));
+    // Outputs were written THROUGH L2, so once a wave's stores have drained (vmcnt 0) they are in memory: no
+    // device-scope release fence — which on this multi-XCD part is an L2 write-back per call, 15x the whole pass when
+    // every block does one — is needed before counting the block in.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                       // every wave of the block has drained (early-returned threads included)
+    if (threadIdx.x == 0) {
+        if (__hip_atomic_fetch_add(&f.count[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == nb)
+            __hip_atomic_store(&f.flag[b], f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -647,7 +694,28 @@ static int launch_tiled_r(const LaunchDesc &d, const TiledParams &p, dim3 grid, 
     return MI_BLUR_ERR_INVALID;
 }
 
-static int launch_tiled(const LaunchDesc &d, bool ragged = false)
+template <int R>
+static int launch_fused_r(const LaunchDesc &d, const TiledParams &p, const FusedParams &f, dim3 grid, dim3 block, size_t lds, int rpg)
+{
+    auto go = [&](auto kernel) {
+        if (d.start || d.stop) hipExtLaunchKernelGGL(kernel, grid, block, lds, d.stream, d.start, d.stop, 0, p, f);
+        else hipLaunchKernelGGL(kernel, grid, block, lds, d.stream, p, f);
+        return hip_status(hipGetLastError());
+    };
+    switch (d.channels * 10 + rpg) {
+    case 14: return go(blur_fused_kernel<1, R, 4>);
+    case 18: return go(blur_fused_kernel<1, R, 8>);
+    case 24: return go(blur_fused_kernel<2, R, 4>);
+    case 28: return go(blur_fused_kernel<2, R, 8>);
+    case 34: return go(blur_fused_kernel<3, R, 4>);
+    case 38: return go(blur_fused_kernel<3, R, 8>);
+    case 44: return go(blur_fused_kernel<4, R, 4>);
+    case 48: return go(blur_fused_kernel<4, R, 8>);
+    }
+    return MI_BLUR_ERR_INVALID;
+}
+
+static int launch_tiled(const LaunchDesc &d, bool ragged = false, const FusedDesc *fused = nullptr)
 {
     const Tunables &tun = tunables();
     const int R = d.radius;
@@ -660,7 +728,7 @@ static int launch_tiled(const LaunchDesc &d, bool ragged = false)
         const long long waves8 = (long long)d.n_images * rows * cpr / (8 * 64);
         rpg = waves8 < 16384 ? 4 : 8;
     }
-    if (ragged && rpg == 16) rpg = 8;
+    if ((ragged || fused) && rpg == 16) rpg = 8;
 
     TiledParams p{};
     p.in = d.in; p.out = d.out;
@@ -694,8 +762,27 @@ static int launch_tiled(const LaunchDesc &d, bool ragged = false)
 
     const dim3 grid((unsigned)nblocks), block((unsigned)((p.ncols * p.ngroups + 63) / 64 * 64));
     const size_t lds = (size_t)(p.TH + 2 * R) * (p.ncols + 2) * 16;
+    if (fused) {
+        FusedParams f{};
+        f.count = fused->count; f.flag = fused->flag; f.epoch = fused->epoch;
+        const long long tpb = (long long)fused->batch_images * p.ntiles_y * p.nstrips;
+        if (tpb <= 0 || tpb > 0x7fffffffLL) return MI_BLUR_ERR_INVALID;
+        f.tiles_per_batch = (unsigned)tpb;
+        p.debug_copy = 0;
+        return R == 1 ? launch_fused_r<1>(d, p, f, grid, block, lds, rpg) : launch_fused_r<2>(d, p, f, grid, block, lds, rpg);
+    }
     return R == 1 ? launch_tiled_r<1>(d, p, grid, block, lds, rpg, tun.stage_dma != 0, ragged)
                   : launch_tiled_r<2>(d, p, grid, block, lds, rpg, tun.stage_dma != 0, ragged);
+}
+
+int launch_fused(const LaunchDesc &d, const FusedDesc &f)
+{
+    if (!d.in || !d.out || d.in == d.out || !f.count || !f.flag || f.batch_images <= 0) return MI_BLUR_ERR_INVALID;
+    if (d.width <= 0 || d.band_rows <= 0 || d.n_images <= 0 || (d.radius != 1 && d.radius != 2)) return MI_BLUR_ERR_INVALID;
+    if (d.y0 != 0 || d.y1 != d.band_rows || d.in_stride || d.out_stride) return MI_BLUR_ERR_INVALID;
+    if ((long long)d.width * d.channels * d.band_rows > INT_MAX) return MI_BLUR_ERR_INVALID;
+    if (!tiled_eligible(d.in, d.out, d.width, d.channels)) return MI_BLUR_ERR_UNSUPPORTED;
+    return launch_tiled(d, false, &f);
 }
 
 static int launch_stream(const LaunchDesc &d)

@@ -22,6 +22,12 @@ struct LaunchDesc {
 // Returns MI_BLUR_OK or a negative mi_blur_status.
 int launch(const LaunchDesc &d);
 
+// Fused stream (blur_fused_kernel): one dispatch over d.n_images images whose blocks are ordered in batches of
+// batch_images; batch b's last block stores `epoch` to flag[b] (host-visible).  count[] (device) must be zero.
+// Aligned tiled shapes only (MI_BLUR_ERR_UNSUPPORTED otherwise).
+struct FusedDesc { unsigned *count; unsigned *flag; int batch_images; unsigned epoch; };
+int launch_fused(const LaunchDesc &d, const FusedDesc &f);
+
 // Planar (CImg storage: plane c of image i at (i*C + c)*W*H) <-> interleaved repack, layout_kernels.hip.
 int launch_planar_to_interleaved(const uint8_t *src, uint8_t *dst, int width, int height, int channels, int n_images, hipStream_t s);
 int launch_interleaved_to_planar(const uint8_t *src, uint8_t *dst, int width, int height, int channels, int n_images, hipStream_t s);

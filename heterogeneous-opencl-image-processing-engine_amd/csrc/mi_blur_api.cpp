@@ -180,6 +180,10 @@ struct mi_blur_ctx {
     size_t ev_used = 0;
     uint64_t timed_launches = 0, timed_bytes_alg = 0;   // resident launches that carried timestamp events
     uint64_t zero_copy_launches = 0;
+    // fused stream: per-batch completion counters (device) and flags (pinned host memory)
+    unsigned *fused_count = nullptr, *fused_flag = nullptr;
+    int fused_cap = 0, fused_batches = 0;
+    unsigned fused_epoch = 0;
     // CPU device
     std::vector<CpuJob *> cpu_jobs;
     bool is_cpu() const { return device == MI_BLUR_DEVICE_CPU; }
@@ -370,6 +374,8 @@ extern "C" void mi_blur_destroy(mi_blur_ctx *c)
         for (auto &s : c->slots) { if (s.stream) (void)hipStreamSynchronize(s.stream); }
         for (auto &s : c->slots) free_slot(s);
         for (auto &t : c->ev_pool) { (void)hipEventDestroy(t.s); (void)hipEventDestroy(t.e); }
+        if (c->fused_count) (void)hipFree(c->fused_count);
+        if (c->fused_flag) (void)hipHostFree(c->fused_flag);
         if (c->pool_in) (void)hipFree(c->pool_in);
         if (c->pool_out) (void)hipFree(c->pool_out);
         (void)hipGetLastError();
@@ -623,6 +629,66 @@ extern "C" int mi_blur_resident_run(mi_blur_ctx *c, int n_images, int batch, int
     c->tm.images += (uint64_t)n_images;
     c->tm.bytes_alg += 2ull * c->image_bytes * (uint64_t)n_images;
     return MI_BLUR_OK;
+}
+
+// The same pass as ONE dispatch (blur_fused_kernel): the GPU walks the batches in order and raises a host-visible
+// flag per finished batch, so the batch stays the unit of completion without being the unit of dispatch.
+extern "C" int mi_blur_resident_run_fused(mi_blur_ctx *c, int n_images, int batch, int timed)
+{
+    if (!c || n_images <= 0 || batch <= 0) return MI_BLUR_ERR_INVALID;
+    if (c->is_cpu() || !c->pool_in) return MI_BLUR_ERR_STATE;
+    if (n_images > c->pool_images) return MI_BLUR_ERR_INVALID;           // one contiguous run of the pool
+    HIP_TRY(hipSetDevice(c->device));
+    const int nb = (n_images + batch - 1) / batch;
+    if (nb > c->fused_cap) {
+        // the previous pass may still be writing its flags
+        for (auto &s : c->slots) HIP_TRY(hipStreamSynchronize(s.stream));
+        if (c->fused_count) { (void)hipFree(c->fused_count); c->fused_count = nullptr; }
+        if (c->fused_flag) { (void)hipHostFree(c->fused_flag); c->fused_flag = nullptr; }
+        c->fused_cap = 0;
+        HIP_TRY(hipMalloc((void **)&c->fused_count, sizeof(unsigned) * (size_t)nb));
+        HIP_TRY(hipHostMalloc((void **)&c->fused_flag, sizeof(unsigned) * (size_t)nb, hipHostMallocPortable | hipHostMallocMapped));
+        memset(c->fused_flag, 0, sizeof(unsigned) * (size_t)nb);
+        c->fused_cap = nb;
+    }
+    if (c->cursor + n_images > c->pool_images) c->cursor = 0;
+    Slot &s = c->slots[0];
+    HIP_TRY(hipMemsetAsync(c->fused_count, 0, sizeof(unsigned) * (size_t)nb, s.stream));
+    c->fused_epoch += 1;
+    c->fused_batches = nb;
+    LaunchDesc d{};
+    d.in = c->pool_in + (size_t)c->cursor * c->image_bytes;
+    d.out = c->pool_out + (size_t)c->cursor * c->image_bytes;
+    d.width = c->W; d.band_rows = c->H; d.channels = c->C; d.radius = c->R; d.n_images = n_images;
+    d.y0 = 0; d.y1 = c->H; d.variant = MI_BLUR_VARIANT_TILED; d.stream = s.stream;
+    if (timed) {
+        if (c->ev_used == c->ev_pool.size()) {
+            TimedLaunch t{};
+            HIP_TRY(hipEventCreate(&t.s));
+            HIP_TRY(hipEventCreate(&t.e));
+            c->ev_pool.push_back(t);
+        }
+        d.start = c->ev_pool[c->ev_used].s; d.stop = c->ev_pool[c->ev_used].e;
+        c->ev_used++;
+    }
+    FusedDesc f{c->fused_count, c->fused_flag, batch, c->fused_epoch};
+    int rc = launch_fused(d, f);
+    if (rc) return rc;
+    c->cursor += n_images;
+    c->tm.launches += 1;
+    c->tm.images += (uint64_t)n_images;
+    c->tm.bytes_alg += 2ull * c->image_bytes * (uint64_t)n_images;
+    if (timed) { c->timed_launches += 1; c->timed_bytes_alg += 2ull * c->image_bytes * (uint64_t)n_images; }
+    return MI_BLUR_OK;
+}
+
+// Non-blocking: how many LEADING batches of the latest fused pass are complete (their outputs are in the pool).
+extern "C" int mi_blur_resident_batches_done(mi_blur_ctx *c)
+{
+    if (!c || !c->fused_flag) return 0;
+    int n = 0;
+    while (n < c->fused_batches && __atomic_load_n(&c->fused_flag[n], __ATOMIC_ACQUIRE) == c->fused_epoch) n++;
+    return n;
 }
 
 // ----------------------------------------------------------------------------------

@@ -665,3 +665,48 @@ def test_single_image_near_the_2gib_limit(pkg, L, O, torch_cuda, W, H):
             assert np.array_equal(d_out[r0:r0 + 8].cpu().numpy(), ref[a:a + 8]), (radius, r0)
     d_big = torch.empty(8, dtype=torch.uint8, device="cuda")   # never touched: the call must be refused up front
     assert L.mi_blur_enqueue_ex(d_big.data_ptr(), d_out.data_ptr(), W, H + 1, c, 1, 1, 0, H + 1, 0, None) == pkg.ERR_INVALID
+
+
+def test_fused_stream_parity_and_batch_flags(pkg, L, O, torch_cuda):
+    """mi_blur_resident_run_fused: one dispatch for the pass, batch = unit of completion.  Every image equals the oracle
+    (3x3 and 5x5, full and short last batch, repeated passes = epochs); the done-count is monotone, never exceeds the
+    number of batches, reaches it after sync, and a batch reported done has its outputs in the pool."""
+    for (h, w, c, r, n, batch) in [(64, 64, 3, 1, 250, 35), (48, 80, 4, 2, 77, 10), (256, 256, 3, 1, 1500, 35), (32, 16, 1, 1, 9, 20)]:
+        with pkg.Context(0, w, h, c, r, max_batch=1, n_slots=2) as ctx:
+            ctx.resident_alloc(n)
+            ctx.resident_fill_synthetic(7)
+            nb = (n + batch - 1) // batch
+            src = O.lcg_stream(n, h, w, c, first_index=7)
+            want = O.blur_batch(src, r)
+            for rep in range(3):
+                ctx.resident_run_fused(n, batch, timed=(rep == 1))
+                seen = []
+                for _ in range(50):
+                    seen.append(ctx.resident_batches_done())
+                tm = ctx.sync()
+                seen.append(ctx.resident_batches_done())
+                assert all(0 <= a <= b2 <= nb for a, b2 in zip(seen, seen[1:])), seen
+                assert seen[-1] == nb
+                out = np.zeros_like(src)
+                ctx.resident_download(0, out.ctypes.data, n)
+                assert np.array_equal(out, want), (h, w, c, r, rep)
+            assert tm["launches"] == 3 and tm["images"] == 3 * n and tm["kernel_ms"] > 0
+            assert ctx.timed_coverage() == (1, 2 * n * h * w * c)
+    # the headline shape: poll until the first batches are flagged (this returns while the dispatch is typically still
+    # running), then read batch 0 back (resident_download waits for the device) and compare
+    h, w, c, n, batch = 256, 256, 3, 5000, 35
+    with pkg.Context(0, w, h, c, 1, max_batch=1, n_slots=2) as ctx:
+        ctx.resident_alloc(n)
+        ctx.resident_fill_synthetic(0)
+        ctx.resident_run_fused(n, batch)
+        done = 0
+        while done < 3:
+            done = ctx.resident_batches_done()
+        got = np.zeros((batch, h, w, c), np.uint8)
+        ctx.resident_download(0, got.ctypes.data, batch)
+        ctx.sync()
+        assert np.array_equal(got, O.blur_batch(O.lcg_stream(batch, h, w, c), 1))
+    # ragged rows are not taken by the fused form
+    with pkg.Context(0, 17, 9, 3, 1, max_batch=1, n_slots=1) as ctx:
+        ctx.resident_alloc(4)
+        assert L.mi_blur_resident_run_fused(ctx.h, 4, 2, 0) == pkg.ERR_UNSUPPORTED
