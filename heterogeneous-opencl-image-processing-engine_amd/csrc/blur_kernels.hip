@@ -240,7 +240,7 @@ __device__ __forceinline__ void store16_write_through(uint8_t *q, u32x4 v)
 {
     // s_nop: a store of more than 8 bytes needs two wait states before a VALU may overwrite its data registers; the
     // compiler's hazard pass does not look inside inline asm
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(q), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(q), "v"(v) : "memory");
 }
 
 // One workgroup's tile (tile number L of the launch).  Threads may return early; the only barrier is after staging.
@@ -395,14 +395,15 @@ __global__ __launch_bounds__(256) void blur_tiled_kernel(const TiledParams p)
 }
 
 // Fused stream: ONE dispatch for a whole pass of the resident stream, with the batch kept as the unit of completion.
-// Blocks are ordered batch by batch (XCD-contiguous inside a batch's window of tiles); the last block of a batch to
-// finish raises that batch's flag in host-visible memory, so a consumer sees batches complete in stream order while
-// the GPU never pays a per-batch dispatch (4 us floor + ~3.5 us of dispatch processing each).
+// Blocks are ordered batch by batch (XCD-contiguous inside a batch's window of tiles); every wave, once its own output
+// stores have drained, meets the rest of its block at a barrier; one thread then adds 1 to the batch's counter with a
+// fire-and-forget atomic (one of 8 per batch).  The host reads the counters: a batch is complete when they sum to its
+// number of blocks.  A consumer
+// therefore sees batches complete in stream order while the GPU never pays a per-batch dispatch (4 us floor + ~3.5 us
+// of dispatch processing each).
 struct FusedParams {
-    unsigned *count;          // device, one counter per batch, zeroed before the launch
-    unsigned *flag;           // host-visible (pinned), one word per batch: set to `epoch` when the batch is complete
+    unsigned *count;          // device, EIGHT counters per batch (spread by block number: less contention), zeroed before the launch
     unsigned tiles_per_batch; // batch_images * tiles per image
-    unsigned epoch;
 };
 
 template <int C, int R, int RPG>
@@ -412,15 +413,12 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(const TiledParams p, co
     const unsigned nb = min(f.tiles_per_batch, p.nblocks - base);          // the last batch may be short
     const unsigned w = blockIdx.x - base;
     tiled_tile<C, R, RPG, true, false, false, true>(p, base + (p.xcd && nb >= 16 ? xcd_contiguous(w, nb) : w));
-    // Outputs were written THROUGH L2, so once a wave's stores have drained (vmcnt 0) they are in memory: no
-    // device-scope release fence — which on this multi-XCD part is an L2 write-back per call, 15x the whole pass when
-    // every block does one — is needed before counting the block in.
+    // Outputs were written THROUGH L2 (the XCDs' L2s are not coherent with each other), so once this wave's stores
+    // have drained they are in memory.  No device-scope release fence (an L2 write-back per call: 15x the whole pass when
+    // every block does one), no returning atomic (its round trip would keep the block's LDS allocated).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                       // every wave of the block has drained (early-returned threads included)
-    if (threadIdx.x == 0) {
-        if (__hip_atomic_fetch_add(&f.count[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == nb)
-            __hip_atomic_store(&f.flag[b], f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    __syncthreads();                       // every wave of the block has drained (one atomic per block: the counters are hot spots)
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&f.count[b * 8u + (w & 7u)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ----------------------------------------------------------------------------------
@@ -764,10 +762,13 @@ static int launch_tiled(const LaunchDesc &d, bool ragged = false, const FusedDes
     const size_t lds = (size_t)(p.TH + 2 * R) * (p.ncols + 2) * 16;
     if (fused) {
         FusedParams f{};
-        f.count = fused->count; f.flag = fused->flag; f.epoch = fused->epoch;
+        f.count = fused->count;
         const long long tpb = (long long)fused->batch_images * p.ntiles_y * p.nstrips;
         if (tpb <= 0 || tpb > 0x7fffffffLL) return MI_BLUR_ERR_INVALID;
         f.tiles_per_batch = (unsigned)tpb;
+        if (fused->tiles_per_batch) *fused->tiles_per_batch = (unsigned)tpb;
+        if (fused->waves_per_block) *fused->waves_per_block = 1;      // one count per block
+        if (fused->total_blocks) *fused->total_blocks = (unsigned)nblocks;
         p.debug_copy = 0;
         return R == 1 ? launch_fused_r<1>(d, p, f, grid, block, lds, rpg) : launch_fused_r<2>(d, p, f, grid, block, lds, rpg);
     }
@@ -777,7 +778,7 @@ static int launch_tiled(const LaunchDesc &d, bool ragged = false, const FusedDes
 
 int launch_fused(const LaunchDesc &d, const FusedDesc &f)
 {
-    if (!d.in || !d.out || d.in == d.out || !f.count || !f.flag || f.batch_images <= 0) return MI_BLUR_ERR_INVALID;
+    if (!d.in || !d.out || d.in == d.out || !f.count || f.batch_images <= 0) return MI_BLUR_ERR_INVALID;
     if (d.width <= 0 || d.band_rows <= 0 || d.n_images <= 0 || (d.radius != 1 && d.radius != 2)) return MI_BLUR_ERR_INVALID;
     if (d.y0 != 0 || d.y1 != d.band_rows || d.in_stride || d.out_stride) return MI_BLUR_ERR_INVALID;
     if ((long long)d.width * d.channels * d.band_rows > INT_MAX) return MI_BLUR_ERR_INVALID;

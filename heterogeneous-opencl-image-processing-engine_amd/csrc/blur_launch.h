@@ -23,9 +23,11 @@ struct LaunchDesc {
 int launch(const LaunchDesc &d);
 
 // Fused stream (blur_fused_kernel): one dispatch over d.n_images images whose blocks are ordered in batches of
-// batch_images; batch b's last block stores `epoch` to flag[b] (host-visible).  count[] (device) must be zero.
+// batch_images; every block of batch b adds *waves_per_block (1) to one of count[8b .. 8b+7] (device, zeroed by the
+// caller) after its stores have drained, so batch b is complete when those eight sum to its blocks (geometry outputs:
+// a full batch has *tiles_per_batch blocks, the last one what is left of *total_blocks).
 // Aligned tiled shapes only (MI_BLUR_ERR_UNSUPPORTED otherwise).
-struct FusedDesc { unsigned *count; unsigned *flag; int batch_images; unsigned epoch; };
+struct FusedDesc { unsigned *count; int batch_images; unsigned *tiles_per_batch, *waves_per_block, *total_blocks; };
 int launch_fused(const LaunchDesc &d, const FusedDesc &f);
 
 // Planar (CImg storage: plane c of image i at (i*C + c)*W*H) <-> interleaved repack, layout_kernels.hip.

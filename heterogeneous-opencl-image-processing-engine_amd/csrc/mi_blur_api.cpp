@@ -181,9 +181,10 @@ struct mi_blur_ctx {
     uint64_t timed_launches = 0, timed_bytes_alg = 0;   // resident launches that carried timestamp events
     uint64_t zero_copy_launches = 0;
     // fused stream: per-batch completion counters (device) and flags (pinned host memory)
-    unsigned *fused_count = nullptr, *fused_flag = nullptr;
+    unsigned *fused_count = nullptr, *fused_host = nullptr;    // device counters; pinned host copy for polling
     int fused_cap = 0, fused_batches = 0;
-    unsigned fused_epoch = 0;
+    unsigned fused_tpb = 0, fused_wpb = 0, fused_blocks = 0;     // geometry of the latest fused pass
+    hipStream_t fused_poll = nullptr;
     // CPU device
     std::vector<CpuJob *> cpu_jobs;
     bool is_cpu() const { return device == MI_BLUR_DEVICE_CPU; }
@@ -375,7 +376,8 @@ extern "C" void mi_blur_destroy(mi_blur_ctx *c)
         for (auto &s : c->slots) free_slot(s);
         for (auto &t : c->ev_pool) { (void)hipEventDestroy(t.s); (void)hipEventDestroy(t.e); }
         if (c->fused_count) (void)hipFree(c->fused_count);
-        if (c->fused_flag) (void)hipHostFree(c->fused_flag);
+        if (c->fused_host) (void)hipHostFree(c->fused_host);
+        if (c->fused_poll) (void)hipStreamDestroy(c->fused_poll);
         if (c->pool_in) (void)hipFree(c->pool_in);
         if (c->pool_out) (void)hipFree(c->pool_out);
         (void)hipGetLastError();
@@ -644,17 +646,16 @@ extern "C" int mi_blur_resident_run_fused(mi_blur_ctx *c, int n_images, int batc
         // the previous pass may still be writing its flags
         for (auto &s : c->slots) HIP_TRY(hipStreamSynchronize(s.stream));
         if (c->fused_count) { (void)hipFree(c->fused_count); c->fused_count = nullptr; }
-        if (c->fused_flag) { (void)hipHostFree(c->fused_flag); c->fused_flag = nullptr; }
+        if (c->fused_host) { (void)hipHostFree(c->fused_host); c->fused_host = nullptr; }
         c->fused_cap = 0;
-        HIP_TRY(hipMalloc((void **)&c->fused_count, sizeof(unsigned) * (size_t)nb));
-        HIP_TRY(hipHostMalloc((void **)&c->fused_flag, sizeof(unsigned) * (size_t)nb, hipHostMallocPortable | hipHostMallocMapped));
-        memset(c->fused_flag, 0, sizeof(unsigned) * (size_t)nb);
+        HIP_TRY(hipMalloc((void **)&c->fused_count, sizeof(unsigned) * 8 * (size_t)nb));
+        HIP_TRY(hipHostMalloc((void **)&c->fused_host, sizeof(unsigned) * 8 * (size_t)nb, hipHostMallocDefault));
         c->fused_cap = nb;
     }
+    if (!c->fused_poll) HIP_TRY(hipStreamCreateWithFlags(&c->fused_poll, hipStreamNonBlocking));
     if (c->cursor + n_images > c->pool_images) c->cursor = 0;
     Slot &s = c->slots[0];
-    HIP_TRY(hipMemsetAsync(c->fused_count, 0, sizeof(unsigned) * (size_t)nb, s.stream));
-    c->fused_epoch += 1;
+    HIP_TRY(hipMemsetAsync(c->fused_count, 0, sizeof(unsigned) * 8 * (size_t)nb, s.stream));
     c->fused_batches = nb;
     LaunchDesc d{};
     d.in = c->pool_in + (size_t)c->cursor * c->image_bytes;
@@ -671,7 +672,7 @@ extern "C" int mi_blur_resident_run_fused(mi_blur_ctx *c, int n_images, int batc
         d.start = c->ev_pool[c->ev_used].s; d.stop = c->ev_pool[c->ev_used].e;
         c->ev_used++;
     }
-    FusedDesc f{c->fused_count, c->fused_flag, batch, c->fused_epoch};
+    FusedDesc f{c->fused_count, batch, &c->fused_tpb, &c->fused_wpb, &c->fused_blocks};
     int rc = launch_fused(d, f);
     if (rc) return rc;
     c->cursor += n_images;
@@ -685,9 +686,19 @@ extern "C" int mi_blur_resident_run_fused(mi_blur_ctx *c, int n_images, int batc
 // Non-blocking: how many LEADING batches of the latest fused pass are complete (their outputs are in the pool).
 extern "C" int mi_blur_resident_batches_done(mi_blur_ctx *c)
 {
-    if (!c || !c->fused_flag) return 0;
+    if (!c || !c->fused_count || !c->fused_batches) return 0;
+    // read the counters on a stream of their own (the pass may still be running on the compute stream)
+    if (hipSetDevice(c->device) != hipSuccess ||
+        hipMemcpyAsync(c->fused_host, c->fused_count, sizeof(unsigned) * 8 * (size_t)c->fused_batches, hipMemcpyDeviceToHost, c->fused_poll) != hipSuccess ||
+        hipStreamSynchronize(c->fused_poll) != hipSuccess) { (void)hipGetLastError(); return 0; }
     int n = 0;
-    while (n < c->fused_batches && __atomic_load_n(&c->fused_flag[n], __ATOMIC_ACQUIRE) == c->fused_epoch) n++;
+    for (; n < c->fused_batches; n++) {
+        const unsigned first = (unsigned)n * c->fused_tpb;
+        const unsigned blocks = std::min(c->fused_tpb, c->fused_blocks - first);
+        unsigned sum = 0;
+        for (int k = 0; k < 8; k++) sum += c->fused_host[8 * n + k];
+        if (sum != blocks * c->fused_wpb) break;
+    }
     return n;
 }
 

@@ -217,10 +217,10 @@ void mi_blur_timed_coverage(mi_blur_ctx *ctx, uint64_t *launches, uint64_t *byte
 
 /* The same pass as ONE dispatch ("fused stream").  A batch-35 stream issued launch by launch is bound by the
  * GPU's per-dispatch processing (~3.5 us each over 4 hardware queues), not by the kernel; here the kernel walks
- * the batches itself — blocks ordered batch by batch — and the last block of every batch raises that batch's flag
- * in host-visible memory.  The batch stays the unit of COMPLETION (mi_blur_resident_batches_done counts the
- * leading batches whose outputs are ready, non-blocking, while the dispatch is still running) without being the
- * unit of DISPATCH.  n_images <= pool size (one contiguous run of the pool); aligned tiled shapes only
+ * the batches itself — blocks ordered batch by batch — and every wave counts itself into its batch's counter once
+ * its outputs are in memory.  The batch stays the unit of COMPLETION (mi_blur_resident_batches_done reads the
+ * counters and returns how many leading batches have their outputs ready, without waiting for the dispatch, which
+ * may still be running) without being the unit of DISPATCH.  n_images <= pool size (one contiguous run of the pool); aligned tiled shapes only
  * (MI_BLUR_ERR_UNSUPPORTED otherwise).  timed != 0: the dispatch carries timestamp events like resident_run.
  * Asynchronous; follow with mi_blur_sync. */
 int mi_blur_resident_run_fused(mi_blur_ctx *ctx, int n_images, int batch, int timed);
