@@ -166,6 +166,10 @@ def main() -> None:
     ap.add_argument("--workload", choices=["a1", "hd5", "a2"], default="a1")
     ap.add_argument("--batch", type=int, default=35)
     ap.add_argument("--images", type=int, default=5000, help="images per GPU per step (a1)")
+    ap.add_argument("--dispatch", choices=["fused", "batched"], default="fused",
+                    help="a1: 'fused' = one dispatch per pass whose blocks walk the batches in order and count every finished "
+                         "batch in for the host (mi_blur_resident_run_fused; batch = unit of completion); 'batched' = one launch "
+                         "per batch over --streams HIP streams (mi_blur_resident_run; batch = unit of dispatch)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("MI_BLUR_BENCH_STREAMS", "0")),
                     help="HIP streams the launches alternate over (default: 4 for a1 — small launches whose dispatch floors "
                          "must overlap — and 1 for hd5, whose launches fill the GPU on their own)")
@@ -217,32 +221,45 @@ def main() -> None:
             dist_barrier()
         torch.cuda.synchronize()
 
+    fused = args.workload == "a1" and args.dispatch == "fused" and args.batch < args.images
     if args.streams <= 0:
-        args.streams = 4 if args.workload == "a1" else 1
+        args.streams = 4 if (args.workload == "a1" and not fused) else 1
     extra = {}
-    extra_serial = None
-    fused_line = None
+    other_line, other_key = None, None
     if args.workload in ("a1", "hd5"):
         if args.workload == "a1":
             h, w, c, radius, per_gpu, batch, pool = 256, 256, 3, 1, args.images, args.batch, args.images
-            name = f"{per_gpu}x256x256x3 per GPU, 3x3 blur, Approach-1 image-level dispatch, batch={batch}, device-resident"
+            name = (f"{per_gpu}x256x256x3 per GPU, 3x3 blur, Approach-1 image-level dispatch, batch={batch}, device-resident, "
+                    + ("one fused dispatch per pass with per-batch completion counters" if fused else "one launch per batch"))
         else:
             h, w, c, radius, per_gpu, batch, pool = 1080, 1920, 3, 2, 64, 64, 64
             name = "1920x1080x3, 5x5 blur, pool of 64 distinct resident images, one launch per pass"
         # host threads only generate the synthetic stream; keep ranks from oversubscribing the node between them
         host_threads = max(2, min(32, len(os.sched_getaffinity(0)) // max(world, 1)))
+        # The context that will issue one launch per batch on 4 streams is created FIRST when it is only the secondary
+        # measurement: HIP hands hardware queues to streams in creation order, and 4 streams that do not get 4 distinct
+        # queues run like 2-3 streams (6.8 instead of 10 M img/s).
+        alt = None
+        if world == 1 and fused:
+            alt = pkg.Context(local_rank, w, h, c, radius, max_batch=1, n_slots=4, n_threads=host_threads)
         ctx = pkg.Context(local_rank, w, h, c, radius, max_batch=1, n_slots=args.streams, n_threads=host_threads)   # resident runs use no staging
         ctx.resident_alloc(pool)
         ctx.resident_fill_synthetic(rank * per_gpu)
+        def one_pass(timed):
+            if fused:
+                ctx.resident_run_fused(per_gpu, batch, timed=bool(timed))
+            else:
+                ctx.resident_run(per_gpu, batch, timed=timed)
+
         for _ in range(W):
-            ctx.resident_run(per_gpu, batch, timed=False)
+            one_pass(False)
         ctx.sync()
         ctx.reset_timing()
         barrier_sync()
         t0 = time.perf_counter()
-        time_every = args.time_every if args.workload == "a1" else 1
+        time_every = args.time_every if (args.workload == "a1" and not fused) else 1
         for _ in range(K):
-            ctx.resident_run(per_gpu, batch, timed=time_every)
+            one_pass(time_every)
         torch.cuda.synchronize()
         if world > 1:
             dist_barrier()
@@ -268,46 +285,58 @@ def main() -> None:
                   "reference_published_img_s": REFERENCE_IMG_S,
                   "reference_published_on": "320x240x3, i7-12700 + UHD 770 (CPU+iGPU together)"}
 
-        # ---- N=1: the same launches on ONE stream, every dispatch timestamped, outside the timed region.  With several
-        # streams the per-dispatch duration above includes time-sharing the GPU with the other in-flight dispatches and no
-        # profiler reproduces it (tracing every launch slows the host and un-overlaps them); the serial figure is the
-        # one `rocprofv3 --kernel-trace --stats` agrees with (profiles/).
-        if world == 1 and args.streams > 1 and args.workload == "a1":
-            ser = pkg.Context(local_rank, w, h, c, radius, max_batch=1, n_slots=1, n_threads=host_threads)
-            ser.resident_alloc(pool)
-            ser.resident_fill_synthetic(0)
-            ser.resident_run(per_gpu, batch, timed=False)
-            ser.sync(); ser.reset_timing()
-            for _ in range(3):
-                ser.resident_run(per_gpu, batch, timed=1)
-            ts = ser.sync()
-            sn, sb = ser.timed_coverage()
-            if sn and ts["kernel_ms"] > 0:
-                s_us = ts["kernel_ms"] * 1e3 / sn
-                extra_serial = {"avg_launch_us": round(s_us, 2), "achieved": round(sb / sn / s_us / 1e3, 1),
-                                "frac": round(sb / sn / s_us / 1e3 / HBM_PEAK_GBS, 4), "launches_timed": int(sn),
-                                "note": "same launches on one stream after the timed region (dispatches do not overlap)"}
-            ser.close()
-
-        # ---- N=1, always: the fused stream beside the headline (one dispatch per pass, per-batch completion flags)
+        # ---- N=1, a1: the OTHER dispatch form beside the headline, outside the timed region (same pool shape, own context)
         if world == 1 and args.workload == "a1" and batch < per_gpu:
-            # the same 5000-image pass as ONE dispatch whose blocks walk the batches of 35 in order and flag each finished
-            # batch to the host (batch = unit of completion, not of dispatch)
-            ctx.reset_timing()
-            ctx.resident_run_fused(per_gpu, batch); ctx.sync(); ctx.reset_timing()
-            tf0 = time.perf_counter()
-            for _ in range(20):
-                ctx.resident_run_fused(per_gpu, batch, timed=True)
-            tf = ctx.sync()
-            dtf = time.perf_counter() - tf0
-            fn, fb = ctx.timed_coverage()
-            if fn and tf["kernel_ms"] > 0:
-                f_us = tf["kernel_ms"] * 1e3 / fn
-                fused_line = {"img_s": round(20 * per_gpu / dtf, 0), "batch": batch, "dispatch_us": round(f_us, 1),
-                                                     "achieved_gbs": round(fb / fn / f_us / 1e3, 1),
-                                                     "frac_of_8TBs": round(fb / fn / f_us / 1e3 / HBM_PEAK_GBS, 4),
-                                                     "batches_flagged": ctx.resident_batches_done()}
-            ctx.reset_timing()
+            if fused:
+                # one launch per batch: 4 streams so the ~4 us per-dispatch floors overlap (timestamps on every 32nd
+                # launch), then the same launches on one stream with every dispatch timestamped (the regime
+                # rocprofv3 --stats reproduces: tracing un-overlaps the dispatches)
+                alt.resident_alloc(pool); alt.resident_fill_synthetic(0)
+                for _ in range(max(W, 3)):
+                    alt.resident_run(per_gpu, batch, timed=False)
+                alt.sync(); alt.reset_timing()
+                ta0 = time.perf_counter()
+                for _ in range(K):
+                    alt.resident_run(per_gpu, batch, timed=args.time_every)
+                ta = alt.sync()
+                dta = time.perf_counter() - ta0
+                an, ab = alt.timed_coverage()
+                other_line = {"img_s": round(K * per_gpu / dta, 0), "launches_per_step": (per_gpu + batch - 1) // batch, "streams": 4}
+                if an and ta["kernel_ms"] > 0:
+                    a_us = ta["kernel_ms"] * 1e3 / an
+                    other_line.update({"overlapped_dispatch_us": round(a_us, 2), "overlapped_frac": round(ab / an / a_us / 1e3 / HBM_PEAK_GBS, 4)})
+                alt.close()
+                ser = pkg.Context(local_rank, w, h, c, radius, max_batch=1, n_slots=1, n_threads=host_threads)
+                ser.resident_alloc(pool); ser.resident_fill_synthetic(0)
+                ser.resident_run(per_gpu, batch, timed=False); ser.sync(); ser.reset_timing()
+                for _ in range(3):
+                    ser.resident_run(per_gpu, batch, timed=1)
+                ts = ser.sync()
+                sn, sb = ser.timed_coverage()
+                if sn and ts["kernel_ms"] > 0:
+                    s_us = ts["kernel_ms"] * 1e3 / sn
+                    other_line.update({"serial_dispatch_us": round(s_us, 2), "serial_frac": round(sb / sn / s_us / 1e3 / HBM_PEAK_GBS, 4)})
+                ser.close()
+                other_key = "per_batch_launches"
+            else:
+                alt = pkg.Context(local_rank, w, h, c, radius, max_batch=1, n_slots=1, n_threads=host_threads)
+                alt.resident_alloc(pool); alt.resident_fill_synthetic(0)
+                alt.resident_run_fused(per_gpu, batch); alt.sync(); alt.reset_timing()
+                tf0 = time.perf_counter()
+                for _ in range(20):
+                    alt.resident_run_fused(per_gpu, batch, timed=True)
+                tf = alt.sync()
+                dtf = time.perf_counter() - tf0
+                fn, fb = alt.timed_coverage()
+                other_line = {"img_s": round(20 * per_gpu / dtf, 0), "launches_per_step": 1, "batch": batch,
+                              "batches_counted_in": alt.resident_batches_done()}
+                if fn and tf["kernel_ms"] > 0:
+                    f_us = tf["kernel_ms"] * 1e3 / fn
+                    other_line.update({"dispatch_us": round(f_us, 1), "frac": round(fb / fn / f_us / 1e3 / HBM_PEAK_GBS, 4)})
+                alt.close()
+                other_key = "fused_stream"
+        if fused:
+            config["batches_counted_in_last_pass"] = ctx.resident_batches_done()
 
         # ---- extras at N=1: PCIe-inclusive rate, one-launch (HBM-bound) point, hd5 point
         if world == 1 and args.extra and args.workload == "a1":
@@ -419,20 +448,22 @@ def main() -> None:
                   "rows_per_gpu": owned, "halo_bytes_per_neighbour": radius * pitch}
         base_shape = (H, Wd, c, radius)
 
+    # which committed PMC run (profiles/traffic.json) matches this command's dominant kernel and launch shape
+    traffic_key = args.workload
+    if args.workload == "a1" and not fused:
+        traffic_key = "a1_one_launch" if args.batch >= args.images else ("a1_serial" if args.streams == 1 else "a1_batched")
     achieved = bytes_per_launch / avg_launch_s / 1e9
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_traffic(args.workload),
-                "kernel": "blur_tiled_kernel", "algorithmic_bytes_per_launch": round(bytes_per_launch),
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_traffic(traffic_key),
+                "kernel": "blur_fused_kernel" if fused else "blur_tiled_kernel", "algorithmic_bytes_per_launch": round(bytes_per_launch),
                 "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches_timed": timed_n, "timing": timing_src}
     if args.workload != "a2":
-        # Launches of independent batches overlap on the GPU (one HIP stream each), so a dispatch's own
-        # duration is longer than its share of the step: report the whole-step figure beside it.
+        # With one launch per batch the launches of independent batches overlap on the GPU (one HIP stream each), so a
+        # dispatch's own duration is longer than its share of the step: the whole-step figure is reported beside it.
         step_bytes = 2.0 * h * w * c * per_gpu
         roofline["concurrent_streams"] = args.streams
         roofline["whole_step_gbs_per_gpu"] = round(step_bytes * K / local / 1e9, 1)
         roofline["whole_step_frac"] = round(step_bytes * K / local / 1e9 / HBM_PEAK_GBS, 4)
-        if extra_serial:
-            roofline["serial_dispatch"] = extra_serial
 
     line = {"metric": "images_per_sec", "value": round(value, 1), "unit": "img/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True,
@@ -444,8 +475,8 @@ def main() -> None:
             if args.workload == "a2":
                 hh, ww = 1024, 8192           # a band-sized slice of the same image keeps the sample bounded
             line["cpu_baseline"] = cpu_baseline(5000 if args.workload == "a1" else 64, hh, ww, cc, rr)
-        if fused_line:
-            line["fused_stream"] = fused_line
+        if other_line:
+            line[other_key] = other_line
         if extra:
             line["extra"] = extra
         print(json.dumps(line), flush=True)

@@ -24,8 +24,9 @@ run_cfg() {   # name, bench args...
     echo "$name write rc=$?"
 }
 
-run_cfg a1                                                                  # the judged command: python bench.py
-run_cfg a1_serial --streams 1 --time-every 4 --no-cpu-baseline               # same launches, one stream: dispatches do not overlap
+run_cfg a1                                                                  # the judged command: python bench.py (fused stream)
+run_cfg a1_batched --dispatch batched --no-cpu-baseline                      # one launch per batch, 4 streams
+run_cfg a1_serial --dispatch batched --streams 1 --time-every 4 --no-cpu-baseline   # same launches, one stream: dispatches do not overlap
 run_cfg a1_one_launch --batch 5000 --streams 1 --time-every 1 --no-cpu-baseline   # whole stream in one launch (HBM-bound point)
 run_cfg hd5 --workload hd5 --streams 1 --no-cpu-baseline                    # BASELINE configs[2]: 1920x1080 5x5
 run_cfg a2_1gpu --workload a2 --no-cpu-baseline                             # BASELINE configs[4] at N=1: 8192x8192 3x3

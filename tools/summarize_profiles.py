@@ -19,7 +19,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "blur_tiled_kernel"
+
 
 
 def newest(pattern):
@@ -43,8 +43,9 @@ def main():
              "| config (bench args) | bench value | bench avg launch µs (dispatch timestamps) | rocprof avg µs (calls) | "
              "alg. bytes/launch | PMC HBM bytes/launch (2·FETCH+WRITE) | PMC/alg | achieved GB/s | frac of 8 TB/s |",
              "|---|---|---|---|---|---|---|---|---|"]
-    workload_of = {"a1": "a1", "a1_serial": "a1_serial", "a1_one_launch": "a1_one_launch", "hd5": "hd5", "a2_1gpu": "a2"}
-    for cfg in ("a1", "a1_serial", "a1_one_launch", "hd5", "a2_1gpu"):
+    workload_of = {"a1": "a1", "a1_batched": "a1_batched", "a1_serial": "a1_serial", "a1_one_launch": "a1_one_launch", "hd5": "hd5",
+                   "a2_1gpu": "a2"}
+    for cfg in ("a1", "a1_batched", "a1_serial", "a1_one_launch", "hd5", "a2_1gpu"):
         bj = os.path.join(src, f"bench_{cfg}.json")
         if not os.path.exists(bj):
             continue
@@ -52,6 +53,7 @@ def main():
         if not text:
             continue
         bench = json.loads(text[-1])
+        KERNEL = bench["roofline"].get("kernel", "blur_tiled_kernel")       # blur_fused_kernel for the fused stream
         shutil.copy(bj, os.path.join(dst, f"{tag}_{cfg}_bench.json"))
         stats = rows(os.path.join(src, f"trace_{cfg}", "*", "*_kernel_stats.csv"))
         f = newest(os.path.join(src, f"trace_{cfg}", "*", "*_kernel_stats.csv"))
