@@ -166,6 +166,8 @@ struct Options {
     std::string save;                    // --save FILE  write the first output image
     int iters = 100;                     // --iters N    (split_image_blur --resident)
     bool iterate = false;                // --iterate    (split_image_blur --resident): blur the previous iteration's output
+    bool fused = false;                  // --fused      (heterogeneous_blur --resident): one dispatch per GPU for the whole stream,
+                                         //              batches counted in as they finish (mi_blur_resident_run_fused)
     bool overlap = false;                // --overlap    (split_image_blur --resident): halo exchange on its own stream, hidden
                                          //              behind the blur of the interior rows; edge rows follow it
     std::string transport = "rccl";      // --transport rccl|p2p  (split_image_blur --resident): halo rows by RCCL or peer copies
@@ -201,6 +203,7 @@ inline int parse_flags(int argc, char **argv, Options &o)
         else if (a == "--iters") o.iters = atoi(next("--iters"));
         else if (a == "--iterate") o.iterate = true;
         else if (a == "--overlap") o.overlap = true;
+        else if (a == "--fused") o.fused = true;
         else if (a == "--transport") { o.transport = next("--transport"); if (o.transport != "rccl" && o.transport != "p2p") { printf("Error: --transport rccl|p2p\n"); exit(-1); } }
         else { printf("Error: unknown option %s\n", a.c_str()); exit(-1); }
     }
@@ -353,7 +356,7 @@ inline Roofline report_roofline(int section, int G, uint64_t bytes_alg, uint64_t
     r.gbps = (double)bytes_alg / (kernel_ms_sum / 1000.0) / 1e9 * G;
     r.frac = r.gbps / (HBM_PEAK_GBS * G);
     printf("%d. MI355X KERNEL ROOFLINE (%d GPU%s)\n", section, G, G > 1 ? "s" : "");
-    printf("   Launches: %llu (one per batch per GPU), avg %.2f us\n", (unsigned long long)launches, kernel_ms_sum * 1000.0 / launches);
+    printf("   Launches: %llu (one per batch per GPU; one per GPU with --fused), avg %.2f us\n", (unsigned long long)launches, kernel_ms_sum * 1000.0 / launches);
     printf("   Algorithmic bytes (2*W*H*C per image): %.2f MB\n", bytes_alg / 1e6);
     printf("   %s: %.0f images/sec, %.1f GB/s = %.1f%% of %.0f GB/s HBM peak\n",
            streams > 1 ? "Per-dispatch rate" : "Kernel-only rate", images / (kernel_ms_sum / 1000.0) * G, r.gbps, r.frac * 100,

@@ -648,11 +648,18 @@ extern "C" int mi_blur_resident_run_fused(mi_blur_ctx *c, int n_images, int batc
         if (c->fused_count) { (void)hipFree(c->fused_count); c->fused_count = nullptr; }
         if (c->fused_host) { (void)hipHostFree(c->fused_host); c->fused_host = nullptr; }
         c->fused_cap = 0;
-        HIP_TRY(hipMalloc((void **)&c->fused_count, sizeof(unsigned) * 8 * (size_t)nb));
-        HIP_TRY(hipHostMalloc((void **)&c->fused_host, sizeof(unsigned) * 8 * (size_t)nb, hipHostMallocDefault));
-        c->fused_cap = nb;
+        const int cap = std::max(nb, c->pool_images);      // enough for any batch size on this pool: never reallocated
+        HIP_TRY(hipMalloc((void **)&c->fused_count, sizeof(unsigned) * 8 * (size_t)cap));
+        HIP_TRY(hipHostMalloc((void **)&c->fused_host, sizeof(unsigned) * 8 * (size_t)cap, hipHostMallocDefault));
+        c->fused_cap = cap;
     }
-    if (!c->fused_poll) HIP_TRY(hipStreamCreateWithFlags(&c->fused_poll, hipStreamNonBlocking));
+    if (!c->fused_poll) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->fused_poll, hipStreamNonBlocking));
+        // the first device-to-host copy of this size class sets up the copy engine's queue (~8 ms): pay it here, not
+        // in the first poll
+        HIP_TRY(hipMemcpyAsync(c->fused_host, c->fused_count, sizeof(unsigned) * 8 * (size_t)c->fused_cap, hipMemcpyDeviceToHost, c->fused_poll));
+        HIP_TRY(hipStreamSynchronize(c->fused_poll));
+    }
     if (c->cursor + n_images > c->pool_images) c->cursor = 0;
     Slot &s = c->slots[0];
     HIP_TRY(hipMemsetAsync(c->fused_count, 0, sizeof(unsigned) * 8 * (size_t)nb, s.stream));
