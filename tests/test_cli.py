@@ -114,6 +114,8 @@ def test_a1_gpu_and_both_modes(apps, O, tmp_path):
     assert np.array_equal(read_ppm(tmp_path / "auto.ppm"), want)
     r = run([het, "gpu", "1.0", "35", "--size", "256x256", "--images", "5000", "--resident"], tmp_path)
     assert r.returncode == 0 and "9. MI355X KERNEL ROOFLINE" in r.stdout, r.stdout + r.stderr
+    r = run([het, "gpu", "1.0", "35", "--size", "256x256", "--images", "5000", "--resident", "--fused"], tmp_path)
+    assert r.returncode == 0 and "one fused dispatch, 143 batches counted in" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.gpu
