@@ -710,3 +710,25 @@ def test_fused_stream_parity_and_batch_flags(pkg, L, O, torch_cuda):
     with pkg.Context(0, 17, 9, 3, 1, max_batch=1, n_slots=1) as ctx:
         ctx.resident_alloc(4)
         assert L.mi_blur_resident_run_fused(ctx.h, 4, 2, 0) == pkg.ERR_UNSUPPORTED
+
+
+def test_fused_stream_random_shapes(pkg, L, O, torch_cuda):
+    """Seeded sweep of the fused stream: aligned shapes, C = 1..4, both radii, batch sizes that do and do not divide the
+    stream, one or several strips per row, fewer tiles per batch than XCDs and many more."""
+    rng = np.random.default_rng(77)
+    for case in range(24):
+        c = int(rng.choice([1, 2, 3, 4]))
+        w = int(rng.integers(1, 120)) * 16 // int(np.gcd(16, c))
+        h = int(rng.integers(1, 90))
+        r = int(rng.choice([1, 2]))
+        n = int(rng.integers(1, 60))
+        batch = int(rng.integers(1, n + 3))
+        with pkg.Context(0, w, h, c, r, max_batch=1, n_slots=1) as ctx:
+            ctx.resident_alloc(n)
+            ctx.resident_fill_synthetic(case)
+            ctx.resident_run_fused(n, batch)
+            ctx.sync()
+            assert ctx.resident_batches_done() == (n + batch - 1) // batch, (case, h, w, c, r, n, batch)
+            out = np.zeros((n, h, w, c), np.uint8)
+            ctx.resident_download(0, out.ctypes.data, n)
+            assert np.array_equal(out, O.blur_batch(O.lcg_stream(n, h, w, c, first_index=case), r)), (case, h, w, c, r, n, batch)
