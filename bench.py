@@ -261,10 +261,10 @@ def main() -> None:
         for _ in range(K):
             one_pass(time_every)
         torch.cuda.synchronize()
-        if world > 1:
-            dist_barrier()
+        local = time.perf_counter() - t0          # this rank's K steps, from the common (barrier + sync) start to its own drain;
+        if world > 1:                             # the closing barrier + sync follow, then MAX over ranks: the job's time is
+            dist_barrier()                        # the slowest rank's, without the barrier's own latency added to every rank
             torch.cuda.synchronize()
-        local = time.perf_counter() - t0
         tm = ctx.sync()
         elapsed = aggregate_max(local, dist if world > 1 else None, dev if backend == "nccl" else None)
         units = per_gpu * world * K
@@ -431,10 +431,10 @@ def main() -> None:
             step()
         ev1.record()
         torch.cuda.synchronize()
-        if world > 1:
-            dist_barrier()
+        local = time.perf_counter() - t0          # this rank's K steps, from the common (barrier + sync) start to its own drain;
+        if world > 1:                             # the closing barrier + sync follow, then MAX over ranks: the job's time is
+            dist_barrier()                        # the slowest rank's, without the barrier's own latency added to every rank
             torch.cuda.synchronize()
-        local = time.perf_counter() - t0
         elapsed = aggregate_max(local, dist if world > 1 else None, dev if backend == "nccl" else None)
         L.mi_blur_comm_destroy(comm)
         units = K
