@@ -161,7 +161,7 @@ def cpu_baseline(n_target: int, h: int, w: int, c: int, radius: int) -> dict:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=["a1", "hd5", "a2"], default="a1")
     ap.add_argument("--batch", type=int, default=35)
