@@ -139,6 +139,7 @@ def lib() -> C.CDLL:
         "mi_blur_get_timing": (C.c_int, [vp, C.c_void_p]),
         "mi_blur_resident_run_fused": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
         "mi_blur_resident_batches_done": (C.c_int, [vp]),
+        "mi_blur_resident_peek": (C.c_int, [vp, C.c_int, u8p, C.c_int]),
         "mi_blur_zero_copy_launches": (C.c_uint64, [vp]),
         "mi_blur_resident_alloc": (i, [vp, i]),
         "mi_blur_resident_fill_synthetic": (i, [vp, i]),
@@ -267,6 +268,9 @@ class Context:
 
     def resident_run_fused(self, n_images: int, batch: int, timed: bool = False) -> None:
         check(lib().mi_blur_resident_run_fused(self.h, n_images, batch, 1 if timed else 0), "mi_blur_resident_run_fused")
+
+    def resident_peek(self, pool_index: int, host_out, n_images: int) -> None:
+        check(lib().mi_blur_resident_peek(self.h, pool_index, host_out, n_images), "mi_blur_resident_peek")
 
     def resident_batches_done(self) -> int:
         return int(lib().mi_blur_resident_batches_done(self.h))

@@ -709,6 +709,19 @@ extern "C" int mi_blur_resident_batches_done(mi_blur_ctx *c)
     return n;
 }
 
+// Read outputs of batches that mi_blur_resident_batches_done has reported, WITHOUT waiting for the dispatch that is
+// still producing the later ones: a copy on the poll stream, which is ordered behind nothing on the compute streams.
+extern "C" int mi_blur_resident_peek(mi_blur_ctx *c, int pool_index, uint8_t *host_out, int n_images)
+{
+    if (!c || !host_out || !c->pool_out || !c->fused_poll) return MI_BLUR_ERR_STATE;
+    if (pool_index < 0 || n_images < 0 || pool_index + n_images > c->pool_images) return MI_BLUR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(host_out, c->pool_out + (size_t)pool_index * c->image_bytes, c->image_bytes * (size_t)n_images,
+                           hipMemcpyDeviceToHost, c->fused_poll));
+    HIP_TRY(hipStreamSynchronize(c->fused_poll));
+    return MI_BLUR_OK;
+}
+
 // ----------------------------------------------------------------------------------
 // CPU device kernel + helpers
 // ----------------------------------------------------------------------------------

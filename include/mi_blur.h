@@ -225,6 +225,9 @@ void mi_blur_timed_coverage(mi_blur_ctx *ctx, uint64_t *launches, uint64_t *byte
  * Asynchronous; follow with mi_blur_sync. */
 int mi_blur_resident_run_fused(mi_blur_ctx *ctx, int n_images, int batch, int timed);
 int mi_blur_resident_batches_done(mi_blur_ctx *ctx);
+/* Copy out outputs of batches already reported done, without waiting for the dispatch that is still producing the
+ * later ones (mi_blur_resident_download waits for the whole device). */
+int mi_blur_resident_peek(mi_blur_ctx *ctx, int pool_index, uint8_t *host_out, int n_images);
 
 /* ------------------------------------------------------------------------
  * CPU device kernel, exposed for the hosts' `cpu` mode and for timing the

@@ -732,3 +732,46 @@ def test_fused_stream_random_shapes(pkg, L, O, torch_cuda):
             out = np.zeros((n, h, w, c), np.uint8)
             ctx.resident_download(0, out.ctypes.data, n)
             assert np.array_equal(out, O.blur_batch(O.lcg_stream(n, h, w, c, first_index=case), r)), (case, h, w, c, r, n, batch)
+
+
+def test_fused_stream_batches_are_readable_as_soon_as_counted(pkg, L, O, torch_cuda):
+    """The point of the per-batch counters: while ONE dispatch is still working through a 40 000-image stream, every batch
+    the poll reports done must already hold its final bytes when read on another stream (mi_blur_resident_peek does not
+    wait for the dispatch).  The output pool is poisoned first (0xEE everywhere: the blur of a constant image), so a batch
+    counted in too early would read as poison."""
+    torch = torch_cuda
+    h, w, c, n, batch = 256, 256, 3, 40000, 35
+    isz = h * w * c
+    nb = (n + batch - 1) // batch
+    with pkg.Context(0, w, h, c, 1, max_batch=1, n_slots=1) as ctx:
+        ctx.resident_alloc(n)
+        ctx.resident_fill_synthetic(0)
+        ctx.resident_run_fused(70, batch); ctx.sync()                       # creates the counters and the poll stream
+        out_ptr = L.mi_blur_resident_out(ctx.h)
+        const_in = torch.full((1000, h, w, c), 0xEE, dtype=torch.uint8, device="cuda")
+        for i in range(0, n, 1000):
+            pkg.check(L.mi_blur_enqueue(const_in.data_ptr(), out_ptr + i * isz, w, h, c, 1, min(1000, n - i), None))
+        torch.cuda.synchronize()
+        got = np.zeros((batch, h, w, c), np.uint8)
+        ctx.resident_peek(n - batch, got.ctypes.data, batch)
+        assert (got == 0xEE).all()
+        ctx.resident_run_fused(n, batch)
+        # capture first (fast: one image per newly reported batch — its LAST image), verify after the dispatch has ended
+        captured, last, in_flight = [], 0, 0
+        while last < nb:
+            done = ctx.resident_batches_done()
+            if done > last:
+                b = done - 1                                                   # the newest batch reported done
+                idx = min((b + 1) * batch, n) - 1
+                one = np.zeros((1, h, w, c), np.uint8)
+                ctx.resident_peek(idx, one.ctypes.data, 1)
+                captured.append((b, idx, one))
+                in_flight += done < nb
+                last = done
+        ctx.sync()
+        assert captured and last == nb
+        for b, idx, one in captured:
+            want = O.blur(O.lcg_stream(1, h, w, c, first_index=idx)[0], 1)
+            assert np.array_equal(one[0], want), f"batch {b} reported done but image {idx} not final"
+        # how many of the samples were taken while the dispatch was still running depends on the host; recorded, not asserted
+        print(f"verified {len(captured)} batches, {in_flight} of them read while the dispatch was still running")
