@@ -273,7 +273,22 @@ class Context:
         check(lib().mi_blur_resident_peek(self.h, pool_index, host_out, n_images), "mi_blur_resident_peek")
 
     def resident_batches_done(self) -> int:
-        return int(lib().mi_blur_resident_batches_done(self.h))
+        """Leading batches of the latest fused pass that are complete; raises on a negative status."""
+        n = int(lib().mi_blur_resident_batches_done(self.h))
+        if n < 0:
+            raise MiBlurError(n, "mi_blur_resident_batches_done")
+        return n
+
+    def wait_batches(self, want: int, timeout_s: float = 30.0) -> int:
+        """Poll until at least `want` leading batches are done; TimeoutError (with the last count) after timeout_s."""
+        import time
+        deadline = time.monotonic() + timeout_s
+        n = self.resident_batches_done()
+        while n < want:
+            if time.monotonic() > deadline:
+                raise TimeoutError(f"fused stream: {n} of {want} batches counted in after {timeout_s:.0f} s")
+            n = self.resident_batches_done()
+        return n
 
     def timed_coverage(self) -> tuple[int, int]:
         n, b = C.c_uint64(), C.c_uint64()

@@ -83,6 +83,7 @@ int main(int argc, char **argv)
 
     // ---------------- load original image (heterogeneous_blur.c:104-137)
     Image img = load_image(input_filename, opt.syn_w, opt.syn_h, opt.syn_c, opt.synthetic);
+    if (!opt.save_input.empty()) save_one_image(opt.save_input.c_str(), img.px.data(), img.width, img.height, img.channels);
     const int width = img.width, height = img.height, channels = img.channels;
     const int radius = opt.ksize == 3 ? 1 : 2;
     printf("Original image loaded: %dx%d, %d channels\n", width, height, channels);
@@ -201,8 +202,11 @@ int main(int argc, char **argv)
         }
         if (opt.verbose) printf("  synchronised after %.2f ms\n", get_time_ms() - time_start_total);
         if (opt.fused) {
-            for (int g = 0; g < G; g++)
-                printf("%s: one fused dispatch, %d batches counted in\n", gpus[g].name.c_str(), mi_blur_resident_batches_done(gpus[g].ctx));
+            for (int g = 0; g < G; g++) {
+                const int counted = mi_blur_resident_batches_done(gpus[g].ctx);       // negative = status: the poll itself failed
+                if (counted < 0) mi_check(counted, "reading the fused stream's batch counters failed");
+                printf("%s: one fused dispatch, %d batches counted in\n", gpus[g].name.c_str(), counted);
+            }
             if (opt.verbose) printf("  polled after %.2f ms\n", get_time_ms() - time_start_total);
             printf("\n");
         } else

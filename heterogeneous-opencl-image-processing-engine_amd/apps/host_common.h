@@ -164,6 +164,7 @@ struct Options {
     bool resident = false;               // --resident   device-resident stream (kernel-only)
     std::string csv;                     // --csv FILE   append one per_run.csv-style row
     std::string save;                    // --save FILE  write the first output image
+    std::string save_input;              // --save-input FILE  write the decoded input image (what the stream is built from)
     int iters = 100;                     // --iters N    (split_image_blur --resident)
     bool iterate = false;                // --iterate    (split_image_blur --resident): blur the previous iteration's output
     bool fused = false;                  // --fused      (heterogeneous_blur --resident): one dispatch per GPU for the whole stream,
@@ -200,6 +201,7 @@ inline int parse_flags(int argc, char **argv, Options &o)
         else if (a == "--resident") o.resident = true;
         else if (a == "--csv") o.csv = next("--csv");
         else if (a == "--save") o.save = next("--save");
+        else if (a == "--save-input") o.save_input = next("--save-input");
         else if (a == "--iters") o.iters = atoi(next("--iters"));
         else if (a == "--iterate") o.iterate = true;
         else if (a == "--overlap") o.overlap = true;

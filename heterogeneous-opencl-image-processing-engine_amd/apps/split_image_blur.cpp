@@ -76,6 +76,7 @@ int main(int argc, char **argv)
 
     // ---------------- load original image (split_image_blur.c:106-139)
     Image img = load_image(input_filename, opt.syn_w, opt.syn_h, opt.syn_c, opt.synthetic);
+    if (!opt.save_input.empty()) save_one_image(opt.save_input.c_str(), img.px.data(), img.width, img.height, img.channels);
     const int width = img.width, height = img.height, channels = img.channels;
     printf("Original image loaded: %dx%d, %d channels\n", width, height, channels);
     const size_t pitch = (size_t)width * channels, image_size = pitch * height;
@@ -301,9 +302,10 @@ static int run_resident(const Options &opt)
     // ev_halo[g] = this step's halos of GPU g are in place.
     std::vector<hipStream_t> xstream(G, nullptr);
     std::vector<hipEvent_t> ev_done(G, nullptr), ev_halo(G, nullptr);
-    bool overlap = opt.overlap && G > 1;
-    for (int g = 0; g < G && overlap; g++) if (owned[g] <= 2 * radius) overlap = false;     // no interior to hide behind
-    if (overlap)
+    bool can_overlap = G > 1;
+    for (int g = 0; g < G && can_overlap; g++) if (owned[g] <= 2 * radius) can_overlap = false;     // no interior to hide behind
+    bool overlap = opt.overlap && can_overlap;
+    if (can_overlap)      // set up even when not asked for: the report times both forms side by side (below)
         for (int g = 0; g < G; g++) {
             HIP_OK(hipSetDevice(devs[g]));
             HIP_OK(hipStreamCreateWithFlags(&xstream[g], hipStreamNonBlocking));
@@ -396,6 +398,59 @@ static int run_resident(const Options &opt)
     const double gbps = 2.0 * pitch * H * opt.iters / (ms / 1000.0) / 1e9;
     printf("   Algorithmic bandwidth (incl. exchange + launch gaps): %.1f GB/s = %.1f%% of %d x %.0f GB/s\n", gbps,
            gbps / (HBM_PEAK_GBS * G) * 100, G, HBM_PEAK_GBS);
+    // Per-step decomposition (device time, stream events; outside the timed loop above): how long the halo exchange and
+    // the band kernel each occupy a GPU's stream, and — when shards have an interior — the same step issued plain and
+    // with the exchange hidden behind the interior rows.  On real xGMI this says whether RCCL latency or the three-launch
+    // overlapped form bounds a step.  Skipped with --iterate (extra steps would advance the blur chain).
+    if (!opt.iterate) {
+        const int n = std::max(1, std::min(opt.iters, 50));
+        std::vector<hipEvent_t> ea(G), eb(G), ec(G);
+        for (int g = 0; g < G; g++) {
+            HIP_OK(hipSetDevice(devs[g]));
+            HIP_OK(hipEventCreate(&ea[g])); HIP_OK(hipEventCreate(&eb[g])); HIP_OK(hipEventCreate(&ec[g]));
+        }
+        std::vector<double> xus(G, 0.0), kus(G, 0.0);
+        std::vector<void *> st(G);
+        for (int g = 0; g < G; g++) st[g] = stream[g];
+        for (int i = 0; i < n; i++) {
+            for (int g = 0; g < G; g++) { HIP_OK(hipSetDevice(devs[g])); HIP_OK(hipEventRecord(ea[g], stream[g])); }
+            mi_check(mi_blur_halo_exchange_all(comm.data(), G, d_band.data(), W, C, owned.data(), radius, st.data()), "halo exchange failed");
+            for (int g = 0; g < G; g++) {
+                HIP_OK(hipSetDevice(devs[g]));
+                HIP_OK(hipEventRecord(eb[g], stream[g]));
+                mi_check(mi_blur_enqueue_band(d_band[g], d_out[g], W, owned[g] + band[g].halo_top + band[g].halo_bottom, C, radius,
+                                              band[g].halo_top, band[g].halo_top + owned[g], stream[g]), "band launch failed");
+                HIP_OK(hipEventRecord(ec[g], stream[g]));
+            }
+            sync_all();
+            for (int g = 0; g < G; g++) {
+                float a = 0.f, b = 0.f;
+                HIP_OK(hipEventElapsedTime(&a, ea[g], eb[g])); HIP_OK(hipEventElapsedTime(&b, eb[g], ec[g]));
+                xus[g] += a * 1e3; kus[g] += b * 1e3;
+            }
+        }
+        printf("   Per-step decomposition (%d instrumented steps, stream events):\n", n);
+        for (int g = 0; g < G; g++)
+            printf("     GPU %d: halo_exchange_us %.2f   band_kernel_us %.2f   (%d rows, kernel alone = %.1f GB/s)\n", g, xus[g] / n, kus[g] / n,
+                   owned[g], kus[g] > 0 ? 2.0 * pitch * owned[g] / (kus[g] / n * 1e-6) / 1e9 : 0.0);
+        if (can_overlap) {
+            double t[2];
+            for (int ov = 0; ov < 2; ov++) {
+                overlap = ov != 0;
+                step(); sync_all();
+                const double a = get_time_ms();
+                for (int i = 0; i < n; i++) step();
+                sync_all();
+                t[ov] = (get_time_ms() - a) * 1e3 / n;
+            }
+            overlap = opt.overlap && can_overlap;
+            printf("     step_us plain %.2f   overlapped %.2f   (wall clock over %d back-to-back steps each)\n", t[0], t[1], n);
+        }
+        for (int g = 0; g < G; g++) {
+            HIP_OK(hipSetDevice(devs[g]));
+            HIP_OK(hipEventDestroy(ea[g])); HIP_OK(hipEventDestroy(eb[g])); HIP_OK(hipEventDestroy(ec[g]));
+        }
+    }
     for (int g = 0; g < G; g++) {
         HIP_OK(hipSetDevice(devs[g]));
         mi_blur_comm_destroy(comm[g]);

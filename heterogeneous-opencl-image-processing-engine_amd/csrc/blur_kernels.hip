@@ -56,6 +56,7 @@
 #include <limits.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 
 namespace mi_blur {
 
@@ -404,6 +405,7 @@ __global__ __launch_bounds__(256) void blur_tiled_kernel(const TiledParams p)
 struct FusedParams {
     unsigned *count;          // device, EIGHT counters per batch (spread by block number: less contention), zeroed before the launch
     unsigned tiles_per_batch; // batch_images * tiles per image
+    int release;              // 1 = release-ordered completion add (agent scope): the architectural form, ~6x slower
 };
 
 template <int C, int R, int RPG>
@@ -418,7 +420,10 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(const TiledParams p, co
     // every block does one), no returning atomic (its round trip would keep the block's LDS allocated).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                       // every wave of the block has drained (one atomic per block: the counters are hot spots)
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(&f.count[b * 8u + (w & 7u)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+        if (f.release) __hip_atomic_fetch_add(&f.count[b * 8u + (w & 7u)], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_fetch_add(&f.count[b * 8u + (w & 7u)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ----------------------------------------------------------------------------------
@@ -616,16 +621,27 @@ __global__ __launch_bounds__(256) void blur_generic_kernel(const GenericParams p
 // ----------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------
-Tunables &tunables()
+static std::mutex &tunables_mutex() { static std::mutex m; return m; }
+static Tunables &tunables_storage()
 {
     static Tunables t = [] {
-        Tunables v{1, 0, 1, 0, 0, 0, 0, 1, 1};  // rpg 0 / stream_bh 0 = choose per launch
+        Tunables v{1, 0, 1, 0, 0, 0, 0, 1, 1, 0};  // rpg 0 / stream_bh 0 = choose per launch
         if (const char *e = getenv("MI_BLUR_STAGE")) v.stage_dma = strcmp(e, "reg") != 0;
         if (const char *e = getenv("MI_BLUR_RPG")) { const int r = atoi(e); v.rpg = (r == 4 || r == 8 || r == 16) ? r : 0; }
         if (const char *e = getenv("MI_BLUR_XCD")) v.xcd_remap = atoi(e) != 0;
         return v;
     }();
     return t;
+}
+Tunables tunables()
+{
+    std::lock_guard<std::mutex> g(tunables_mutex());
+    return tunables_storage();
+}
+void set_tunables(const Tunables &t)
+{
+    std::lock_guard<std::mutex> g(tunables_mutex());
+    tunables_storage() = t;
 }
 
 // The ragged form of the tiled kernel: any pitch of at least one chunk, any pointer alignment.
@@ -655,7 +671,7 @@ static int do_launch(K kernel, dim3 grid, dim3 block, size_t lds, const LaunchDe
 
 template <int C, int R>
 static int launch_tiled_cr(const LaunchDesc &d, const TiledParams &p, dim3 grid, dim3 block, size_t lds,
-                           int rpg, bool dma, bool ragged)
+                           int rpg, bool dma, bool ragged, bool row_shuffle)
 {
     if (ragged) {
         if (dma)
@@ -664,7 +680,7 @@ static int launch_tiled_cr(const LaunchDesc &d, const TiledParams &p, dim3 grid,
         return rpg == 4 ? do_launch(blur_tiled_kernel<C, R, 4, false, false, true>, grid, block, lds, d, p)
                         : do_launch(blur_tiled_kernel<C, R, 8, false, false, true>, grid, block, lds, d, p);
     }
-    if (tunables().row_shuffle && dma) {
+    if (row_shuffle && dma) {
         if (rpg == 16) return do_launch(blur_tiled_kernel<C, R, 16, true, true>, grid, block, lds, d, p);
         if (rpg == 4) return do_launch(blur_tiled_kernel<C, R, 4, true, true>, grid, block, lds, d, p);
         return do_launch(blur_tiled_kernel<C, R, 8, true, true>, grid, block, lds, d, p);
@@ -681,13 +697,13 @@ static int launch_tiled_cr(const LaunchDesc &d, const TiledParams &p, dim3 grid,
 
 template <int R>
 static int launch_tiled_r(const LaunchDesc &d, const TiledParams &p, dim3 grid, dim3 block, size_t lds,
-                          int rpg, bool dma, bool ragged)
+                          int rpg, bool dma, bool ragged, bool row_shuffle)
 {
     switch (d.channels) {
-    case 1: return launch_tiled_cr<1, R>(d, p, grid, block, lds, rpg, dma, ragged);
-    case 2: return launch_tiled_cr<2, R>(d, p, grid, block, lds, rpg, dma, ragged);
-    case 3: return launch_tiled_cr<3, R>(d, p, grid, block, lds, rpg, dma, ragged);
-    case 4: return launch_tiled_cr<4, R>(d, p, grid, block, lds, rpg, dma, ragged);
+    case 1: return launch_tiled_cr<1, R>(d, p, grid, block, lds, rpg, dma, ragged, row_shuffle);
+    case 2: return launch_tiled_cr<2, R>(d, p, grid, block, lds, rpg, dma, ragged, row_shuffle);
+    case 3: return launch_tiled_cr<3, R>(d, p, grid, block, lds, rpg, dma, ragged, row_shuffle);
+    case 4: return launch_tiled_cr<4, R>(d, p, grid, block, lds, rpg, dma, ragged, row_shuffle);
     }
     return MI_BLUR_ERR_INVALID;
 }
@@ -713,9 +729,8 @@ static int launch_fused_r(const LaunchDesc &d, const TiledParams &p, const Fused
     return MI_BLUR_ERR_INVALID;
 }
 
-static int launch_tiled(const LaunchDesc &d, bool ragged = false, const FusedDesc *fused = nullptr)
+static int launch_tiled(const LaunchDesc &d, const Tunables &tun, bool ragged = false, const FusedDesc *fused = nullptr)
 {
-    const Tunables &tun = tunables();
     const int R = d.radius;
     const int pitch = d.width * d.channels, cpr = (pitch + 15) / 16, rows = d.y1 - d.y0;   // ragged: last chunk partial
     // Output rows per thread.  8 amortises the 2R priming rows of the sliding window best when the grid is
@@ -763,32 +778,33 @@ static int launch_tiled(const LaunchDesc &d, bool ragged = false, const FusedDes
     if (fused) {
         FusedParams f{};
         f.count = fused->count;
+        f.release = tun.fused_release;
         const long long tpb = (long long)fused->batch_images * p.ntiles_y * p.nstrips;
         if (tpb <= 0 || tpb > 0x7fffffffLL) return MI_BLUR_ERR_INVALID;
         f.tiles_per_batch = (unsigned)tpb;
         if (fused->tiles_per_batch) *fused->tiles_per_batch = (unsigned)tpb;
         if (fused->waves_per_block) *fused->waves_per_block = 1;      // one count per block
         if (fused->total_blocks) *fused->total_blocks = (unsigned)nblocks;
+        if (fused->geometry_only) return MI_BLUR_OK;
         p.debug_copy = 0;
         return R == 1 ? launch_fused_r<1>(d, p, f, grid, block, lds, rpg) : launch_fused_r<2>(d, p, f, grid, block, lds, rpg);
     }
-    return R == 1 ? launch_tiled_r<1>(d, p, grid, block, lds, rpg, tun.stage_dma != 0, ragged)
-                  : launch_tiled_r<2>(d, p, grid, block, lds, rpg, tun.stage_dma != 0, ragged);
+    return R == 1 ? launch_tiled_r<1>(d, p, grid, block, lds, rpg, tun.stage_dma != 0, ragged, tun.row_shuffle != 0)
+                  : launch_tiled_r<2>(d, p, grid, block, lds, rpg, tun.stage_dma != 0, ragged, tun.row_shuffle != 0);
 }
 
 int launch_fused(const LaunchDesc &d, const FusedDesc &f)
 {
-    if (!d.in || !d.out || d.in == d.out || !f.count || f.batch_images <= 0) return MI_BLUR_ERR_INVALID;
+    if (!d.in || !d.out || d.in == d.out || (!f.count && !f.geometry_only) || f.batch_images <= 0) return MI_BLUR_ERR_INVALID;
     if (d.width <= 0 || d.band_rows <= 0 || d.n_images <= 0 || (d.radius != 1 && d.radius != 2)) return MI_BLUR_ERR_INVALID;
     if (d.y0 != 0 || d.y1 != d.band_rows || d.in_stride || d.out_stride) return MI_BLUR_ERR_INVALID;
     if ((long long)d.width * d.channels * d.band_rows > INT_MAX) return MI_BLUR_ERR_INVALID;
     if (!tiled_eligible(d.in, d.out, d.width, d.channels)) return MI_BLUR_ERR_UNSUPPORTED;
-    return launch_tiled(d, false, &f);
+    return launch_tiled(d, f.tun ? *f.tun : tunables(), false, &f);
 }
 
-static int launch_stream(const LaunchDesc &d)
+static int launch_stream(const LaunchDesc &d, const Tunables &tun)
 {
-    const Tunables &tun = tunables();
     const int pitch = d.width * d.channels, cpr = pitch / 16, rows = d.y1 - d.y0;
     StreamParams p{};
     p.in = d.in; p.out = d.out;
@@ -850,6 +866,7 @@ int launch(const LaunchDesc &d)
     if ((long long)d.width * d.channels > INT_MAX / 2) return MI_BLUR_ERR_INVALID;
     if ((long long)d.width * d.channels * d.band_rows > INT_MAX) return MI_BLUR_ERR_INVALID;  // per-image 32-bit
     if (d.n_images == 0) return MI_BLUR_OK;
+    const Tunables tun = tunables();                  // one coherent set of knobs for this launch
     const bool can_tile = tiled_eligible(d.in, d.out, d.width, d.channels);
     const long long dense_in = (long long)d.band_rows * d.width * d.channels, dense_out = (long long)(d.y1 - d.y0) * d.width * d.channels;
     if ((d.in_stride && d.in_stride != dense_in) || (d.out_stride && d.out_stride != dense_out)) {
@@ -858,16 +875,16 @@ int launch(const LaunchDesc &d)
             return MI_BLUR_ERR_INVALID;
         if (!can_tile || d.in_stride % 16 || d.out_stride % 16) return MI_BLUR_ERR_UNSUPPORTED;
         if (d.variant != MI_BLUR_VARIANT_AUTO && d.variant != MI_BLUR_VARIANT_TILED) return MI_BLUR_ERR_UNSUPPORTED;
-        return launch_tiled(d);
+        return launch_tiled(d, tun);
     }
-    const bool can_rag = ragged_eligible(d.width, d.channels) && tunables().ragged;
+    const bool can_rag = ragged_eligible(d.width, d.channels) && tun.ragged;
     switch (d.variant) {
     case MI_BLUR_VARIANT_AUTO:
-        if (!can_tile) return can_rag ? launch_tiled(d, true) : launch_generic(d);
-        return tunables().prefer_stream ? launch_stream(d) : launch_tiled(d);
+        if (!can_tile) return can_rag ? launch_tiled(d, tun, true) : launch_generic(d);
+        return tun.prefer_stream ? launch_stream(d, tun) : launch_tiled(d, tun);
     case MI_BLUR_VARIANT_GENERIC: return launch_generic(d);
-    case MI_BLUR_VARIANT_TILED: return can_tile ? launch_tiled(d) : can_rag ? launch_tiled(d, true) : MI_BLUR_ERR_INVALID;
-    case MI_BLUR_VARIANT_STREAM: return can_tile ? launch_stream(d) : MI_BLUR_ERR_INVALID;
+    case MI_BLUR_VARIANT_TILED: return can_tile ? launch_tiled(d, tun) : can_rag ? launch_tiled(d, tun, true) : MI_BLUR_ERR_INVALID;
+    case MI_BLUR_VARIANT_STREAM: return can_tile ? launch_stream(d, tun) : MI_BLUR_ERR_INVALID;
     }
     return MI_BLUR_ERR_INVALID;
 }

@@ -27,7 +27,14 @@ int launch(const LaunchDesc &d);
 // caller) after its stores have drained, so batch b is complete when those eight sum to its blocks (geometry outputs:
 // a full batch has *tiles_per_batch blocks, the last one what is left of *total_blocks).
 // Aligned tiled shapes only (MI_BLUR_ERR_UNSUPPORTED otherwise).
-struct FusedDesc { unsigned *count; int batch_images; unsigned *tiles_per_batch, *waves_per_block, *total_blocks; };
+// geometry_only: fill the geometry outputs for these knobs and return without launching (the caller decides from them
+// whether its counters can keep counting up).  tun: the knob set to use (nullptr = the current one); a caller that asks
+// for the geometry first passes the same copy to both calls.
+struct Tunables;
+struct FusedDesc {
+    unsigned *count; int batch_images; unsigned *tiles_per_batch, *waves_per_block, *total_blocks;
+    const Tunables *tun; bool geometry_only;
+};
 int launch_fused(const LaunchDesc &d, const FusedDesc &f);
 
 // Planar (CImg storage: plane c of image i at (i*C + c)*W*H) <-> interleaved repack, layout_kernels.hip.
@@ -37,9 +44,15 @@ int launch_interleaved_to_planar(const uint8_t *src, uint8_t *dst, int width, in
 // True when the LDS-tiled vector kernel can take this shape.
 bool tiled_eligible(const void *in, const void *out, int width, int channels);
 
-// Tunables: defaults from env (MI_BLUR_STAGE=dma|reg, MI_BLUR_RPG=8|16, MI_BLUR_XCD=0|1),
-// changeable at run time through mi_blur_set_option.
-struct Tunables { int stage_dma; int rpg; int xcd_remap; int debug_copy; int row_shuffle; int prefer_stream; int stream_bh; int zero_copy; int ragged; };
-Tunables &tunables();
+// Tunables: defaults from env (MI_BLUR_STAGE=dma|reg, MI_BLUR_RPG=4|8|16, MI_BLUR_XCD=0|1), changeable at run time
+// through mi_blur_set_option.  Process-wide, kept behind a mutex: tunables() returns a coherent COPY and every launch
+// works from the one copy it took when it started, so flipping a knob while another thread launches is not a data race
+// (that launch sees the old set or the new one, never a mix).
+struct Tunables {
+    int stage_dma; int rpg; int xcd_remap; int debug_copy; int row_shuffle; int prefer_stream; int stream_bh; int zero_copy; int ragged;
+    int fused_release;   // fused stream: 1 = the per-block completion add is release-ordered at agent scope (architectural; slow)
+};
+Tunables tunables();
+void set_tunables(const Tunables &t);
 
 }  // namespace mi_blur

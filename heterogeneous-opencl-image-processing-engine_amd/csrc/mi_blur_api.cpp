@@ -77,7 +77,7 @@ extern "C" int mi_blur_device_count(void)
 extern "C" int mi_blur_set_option(const char *key, int value)
 {
     if (!key) return MI_BLUR_ERR_INVALID;
-    Tunables &t = tunables();
+    Tunables t = tunables();      // copy, edit, publish: launches in other threads see the old set or the new one
     if (!strcmp(key, "stage_dma")) t.stage_dma = value != 0;
     else if (!strcmp(key, "rows_per_thread")) { if (value != 0 && value != 4 && value != 8 && value != 16) return MI_BLUR_ERR_INVALID; t.rpg = value; }
     else if (!strcmp(key, "xcd_remap")) t.xcd_remap = value != 0;
@@ -87,7 +87,9 @@ extern "C" int mi_blur_set_option(const char *key, int value)
     else if (!strcmp(key, "zero_copy")) t.zero_copy = value != 0;
     else if (!strcmp(key, "ragged_tiled")) t.ragged = value != 0;
     else if (!strcmp(key, "stream_band_rows")) { if (value < 0 || value > 4096) return MI_BLUR_ERR_INVALID; t.stream_bh = value; }
+    else if (!strcmp(key, "fused_release")) t.fused_release = value != 0;
     else return MI_BLUR_ERR_INVALID;
+    set_tunables(t);
     return MI_BLUR_OK;
 }
 
@@ -421,7 +423,7 @@ static int submit_common(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_o
         // one way at a time and collapse to ~28 GB/s total when H2D and D2H overlap (profiles/r01_zero_copy.txt): +33-40 %
         // images/s end to end.  Zero-copy launches of one context share one in-order stream — two of them in flight at once
         // halve the link rate just like two copies do.
-        if (tunables().zero_copy) {
+        if (tunables().zero_copy) {   // (a copy of the knobs as they are now)
             const uint8_t *zin = pinned_device_ptr(host_in);
             uint8_t *zout = pinned_device_ptr(host_out);
             const bool dense = in_stride == band_in && out_stride == band_out;
@@ -429,9 +431,8 @@ static int submit_common(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_o
                 s.out_staged = false; s.user_out = host_out; s.out_bytes = out_bytes; s.out_band = band_out; s.out_stride = out_stride;
                 s.out_n = n_images;
                 const hipStream_t zs = c->slots[0].stream;     // all zero-copy launches of a context: one in-order stream
-                s.zero_copy = true;                            // one dispatch packet, nothing else: the kernel's own stop
-                                                               // event doubles as the completion event (every extra
-                                                               // hipEventRecord is a barrier packet between two kernels)
+                // one dispatch packet, nothing else: the kernel's own stop event doubles as the completion event (every
+                // extra hipEventRecord is a barrier packet between two kernels)
                 LaunchDesc d{};
                 d.in = zin; d.out = zout; d.width = c->W; d.band_rows = band_rows; d.channels = c->C;
                 d.radius = c->R; d.n_images = n_images; d.y0 = y0; d.y1 = y1; d.variant = MI_BLUR_VARIANT_AUTO;
@@ -439,6 +440,7 @@ static int submit_common(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_o
                 d.stream = zs; d.start = s.ks; d.stop = s.ke;
                 rc = launch(d);
                 if (rc) return rc;
+                s.zero_copy = true;                            // only now: a failed launch leaves the slot idle and staged
                 s.busy = true;
                 c->tm.bytes_h2d += in_bytes; c->tm.bytes_d2h += out_bytes;
                 c->tm.bytes_alg += 2ull * out_bytes;
@@ -449,6 +451,7 @@ static int submit_common(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_o
             }
         }
         const bool in_pinned = is_pinned(host_in);
+        s.zero_copy = false;
         s.out_staged = !is_pinned(host_out);
         s.user_out = host_out; s.out_bytes = out_bytes; s.out_band = band_out; s.out_stride = out_stride; s.out_n = n_images;
         const uint8_t *src = host_in;
@@ -665,20 +668,29 @@ extern "C" int mi_blur_resident_run_fused(mi_blur_ctx *c, int n_images, int batc
     }
     if (c->cursor + n_images > c->pool_images) c->cursor = 0;
     Slot &s = c->slots[0];
-    // Repeated passes of the same shape do not zero the counters (that would be one more dispatch per pass): every pass
-    // adds the same amounts, so batch b of pass p is complete when its counters sum to p x (its blocks).
-    if (n_images == c->fused_n && batch == c->fused_batch && c->fused_passes > 0 && c->fused_passes < (1u << 20)) {
-        c->fused_passes += 1;
-    } else {
-        HIP_TRY(hipMemsetAsync(c->fused_count, 0, sizeof(unsigned) * 8 * (size_t)nb, s.stream));
-        c->fused_n = n_images; c->fused_batch = batch; c->fused_passes = 1;
-    }
-    c->fused_batches = nb;
     LaunchDesc d{};
     d.in = c->pool_in + (size_t)c->cursor * c->image_bytes;
     d.out = c->pool_out + (size_t)c->cursor * c->image_bytes;
     d.width = c->W; d.band_rows = c->H; d.channels = c->C; d.radius = c->R; d.n_images = n_images;
     d.y0 = 0; d.y1 = c->H; d.variant = MI_BLUR_VARIANT_TILED; d.stream = s.stream;
+    // The launch geometry (blocks per batch) depends on the tuning knobs as well as on the shape: take ONE copy of the
+    // knobs, ask for the geometry first, launch with the same copy.
+    const Tunables tun = tunables();
+    unsigned tpb = 0, wpb = 0, blocks = 0;
+    FusedDesc f{c->fused_count, batch, &tpb, &wpb, &blocks, &tun, true};
+    int rc = launch_fused(d, f);
+    if (rc) return rc;
+    // Repeated passes of the same shape AND geometry do not zero the counters (that would be one more dispatch per
+    // pass): every pass adds the same amounts, so batch b of pass p is complete when its counters sum to p x (its blocks).
+    if (n_images == c->fused_n && batch == c->fused_batch && tpb == c->fused_tpb && wpb == c->fused_wpb &&
+        blocks == c->fused_blocks && c->fused_passes > 0 && c->fused_passes < (1u << 20)) {
+        c->fused_passes += 1;
+    } else {
+        HIP_TRY(hipMemsetAsync(c->fused_count, 0, sizeof(unsigned) * 8 * (size_t)nb, s.stream));
+        c->fused_n = n_images; c->fused_batch = batch; c->fused_passes = 1;
+        c->fused_tpb = tpb; c->fused_wpb = wpb; c->fused_blocks = blocks;
+    }
+    c->fused_batches = nb;
     if (timed) {
         if (c->ev_used == c->ev_pool.size()) {
             TimedLaunch t{};
@@ -689,8 +701,8 @@ extern "C" int mi_blur_resident_run_fused(mi_blur_ctx *c, int n_images, int batc
         d.start = c->ev_pool[c->ev_used].s; d.stop = c->ev_pool[c->ev_used].e;
         c->ev_used++;
     }
-    FusedDesc f{c->fused_count, batch, &c->fused_tpb, &c->fused_wpb, &c->fused_blocks};
-    int rc = launch_fused(d, f);
+    f.geometry_only = false;
+    rc = launch_fused(d, f);
     if (rc) { c->fused_passes = 0; c->fused_batches = 0; return rc; }     // nothing ran: zero the counters next time
     c->cursor += n_images;
     c->tm.launches += 1;
@@ -700,14 +712,18 @@ extern "C" int mi_blur_resident_run_fused(mi_blur_ctx *c, int n_images, int batc
     return MI_BLUR_OK;
 }
 
-// Non-blocking: how many LEADING batches of the latest fused pass are complete (their outputs are in the pool).
+// Non-blocking: how many LEADING batches of the latest fused pass are complete (their outputs are in the pool); >= 0.
+// A NEGATIVE value is a mi_blur_status: the counters could not be read (a failed copy, a faulted device), which a
+// polling caller must treat as the end of the poll, not as "none done yet".
 extern "C" int mi_blur_resident_batches_done(mi_blur_ctx *c)
 {
-    if (!c || !c->fused_count || !c->fused_batches) return 0;
+    if (!c) return MI_BLUR_ERR_INVALID;
+    if (c->is_cpu()) return MI_BLUR_ERR_STATE;
+    if (!c->fused_count || !c->fused_batches) return 0;       // no fused pass issued (or the last one failed to launch)
     // read the counters on a stream of their own (the pass may still be running on the compute stream)
-    if (hipSetDevice(c->device) != hipSuccess ||
-        hipMemcpyAsync(c->fused_host, c->fused_count, sizeof(unsigned) * 8 * (size_t)c->fused_batches, hipMemcpyDeviceToHost, c->fused_poll) != hipSuccess ||
-        hipStreamSynchronize(c->fused_poll) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->fused_host, c->fused_count, sizeof(unsigned) * 8 * (size_t)c->fused_batches, hipMemcpyDeviceToHost, c->fused_poll));
+    HIP_TRY(hipStreamSynchronize(c->fused_poll));
     int n = 0;
     for (; n < c->fused_batches; n++) {
         const unsigned first = (unsigned)n * c->fused_tpb;
@@ -905,9 +921,16 @@ extern "C" int mi_blur_comm_init_all(mi_blur_comm **comms, int n_devices, const 
         int rc = nccl_status(r.CommInitAll(raw.data(), n_devices, devs.data()));
         if (rc) return rc;
     }
+    for (int i = 0; i < n_devices; i++) comms[i] = nullptr;
     for (int i = 0; i < n_devices; i++) {
         mi_blur_comm *c = new (std::nothrow) mi_blur_comm;
-        if (!c) return MI_BLUR_ERR_NOMEM;
+        if (!c) {
+            // give back everything made so far: the wrappers already built (each destroys its RCCL communicator)
+            // and the raw communicators that have no wrapper yet
+            for (int j = 0; j < i; j++) { mi_blur_comm_destroy(comms[j]); comms[j] = nullptr; }
+            for (int j = i; j < n_devices; j++) if (raw[j]) (void)rccl().CommDestroy(raw[j]);
+            return MI_BLUR_ERR_NOMEM;
+        }
         c->comm = raw[i]; c->n_ranks = n_devices; c->rank = i; c->device = devs[i];
         comms[i] = c;
     }

@@ -54,13 +54,16 @@ typedef enum mi_blur_variant {
     MI_BLUR_VARIANT_AUTO = 0,        /* LDS-tiled vector kernel when pitch%16==0 && channels<=4, else generic */
     MI_BLUR_VARIANT_GENERIC = 1,     /* one output byte per thread, any shape */
     MI_BLUR_VARIANT_TILED = 2,       /* LDS halo tile + 16-B vector loads (ragged form for odd pitches; _INVALID if C > 4 or rows < 16 B) */
-    MI_BLUR_VARIANT_STREAM = 3       /* barrier-free register sliding window + DPP row pass (same eligibility) */
+    MI_BLUR_VARIANT_STREAM = 3       /* barrier-free: every wave streams its band through a wave-private LDS row ring
+                                        (LDS-DMA, counted vmcnt), sliding window of row sums in registers (same eligibility) */
 } mi_blur_variant;
 
 const char *mi_blur_strerror(int status);
 int mi_blur_version(void);
 
-/* Kernel tuning knobs (A/B benching and tests; defaults are the shipped configuration):
+/* Kernel tuning knobs (A/B benching and tests; defaults are the shipped configuration).  PROCESS-WIDE: a call
+ * publishes a new set of knobs that every launch issued afterwards (by any context, any thread) takes a coherent
+ * copy of; a launch racing with the call uses the old set or the new one, never a mix.
  *   "stage_dma"        1 = stage LDS tiles with global_load_lds (default), 0 = through VGPRs
  *   "rows_per_thread"  0 (default: chosen per launch from the grid size) | 4 | 8 | 16 output rows per thread
  *   "xcd_remap"        1 = XCD-contiguous blockIdx->tile map (default), 0 = identity
@@ -70,7 +73,9 @@ int mi_blur_version(void);
  *   "ragged_tiled"     1 (default) = rows that are not a multiple of 16 bytes / unaligned pointers take the ragged form of the
  *                      tiled kernel; 0 = they take the generic one-byte-per-thread kernel
  *   "zero_copy"        1 (default) = submits whose input AND output are pinned host memory run the kernel on the
- *                      caller's buffers in place (no staging copies); 0 = always H2D -> kernel -> D2H */
+ *                      caller's buffers in place (no staging copies); 0 = always H2D -> kernel -> D2H
+ *   "fused_release"    0 (default) | 1: how a block of the fused stream publishes "my outputs are in memory" — see
+ *                      mi_blur_resident_run_fused */
 int mi_blur_set_option(const char *key, int value);
 
 /* Number of visible HIP devices (0 is a valid answer: CPU-device contexts still work).
@@ -121,7 +126,7 @@ typedef struct mi_blur_timing {      /* cumulative since create / last reset; mi
     uint64_t launches;
 } mi_blur_timing;
 
-/* device: HIP ordinal, or MI_BLUR_DEVICE_CPU (n_threads host threads; 0 = all cores).
+/* device: HIP ordinal, or MI_BLUR_DEVICE_CPU (n_threads host threads; 0 = all cores, at most 16 — ask for more by number).
  * max_batch: largest n_images of one submit.  n_slots: staging slots (>=1; 2-3 lets
  * H2D(n+1), kernel(n) and D2H(n-1) overlap).  Each slot owns a pinned in/out pair,
  * a device in/out pair and one stream. */
@@ -222,8 +227,17 @@ void mi_blur_timed_coverage(mi_blur_ctx *ctx, uint64_t *launches, uint64_t *byte
  * counters and returns how many leading batches have their outputs ready, without waiting for the dispatch, which
  * may still be running) without being the unit of DISPATCH.  n_images <= pool size (one contiguous run of the pool); aligned tiled shapes only
  * (MI_BLUR_ERR_UNSUPPORTED otherwise).  timed != 0: the dispatch carries timestamp events like resident_run.
- * Asynchronous; follow with mi_blur_sync. */
+ * Asynchronous; follow with mi_blur_sync.
+ *
+ * Ordering of "counted" against "readable".  Default ("fused_release" 0): outputs are stored write-through
+ * (global_store ... sc1), every wave drains its stores (s_waitcnt vmcnt(0)), the block meets at a barrier and one lane
+ * adds to the counter with a relaxed agent-scope atomic.  That a batch's outputs are in memory once its count is
+ * visible is MEASURED behaviour of gfx950 / ROCm 7.2 (MI355X_MICROARCH.md, cross-XCD hand-off table), not an
+ * architectural guarantee of the memory model; tests/test_gpu_parity.py checks it mid-dispatch.  "fused_release" 1
+ * makes the add a release at agent scope — the architectural form, ~6x slower per pass (an L2 write-back per block). */
 int mi_blur_resident_run_fused(mi_blur_ctx *ctx, int n_images, int batch, int timed);
+/* >= 0: how many LEADING batches of the latest fused pass are complete.  NEGATIVE: a mi_blur_status — the counters
+ * could not be read (failed copy, faulted device); a polling loop must stop on it, it will not recover by itself. */
 int mi_blur_resident_batches_done(mi_blur_ctx *ctx);
 /* Copy out outputs of batches already reported done, without waiting for the dispatch that is still producing the
  * later ones (mi_blur_resident_download waits for the whole device). */

@@ -16,7 +16,13 @@ Writes
                      image_320x240.jpg and of split_output.jpg (the one saved output the
                      reference ships, split_image_blur.c:548-553) — data, for a loose
                      PSNR sanity check; JPEG-lossy, never bit-exact.
+  "stream" section   the WHOLE headline stream (5000 x 256x256x3, image i = LCG seeded 0x9E3779B9 ^ i)
+                     through the reference kernel: FNV-1a-64 of the 983 040 000 output bytes laid end to end, and the
+                     FNV of the 5000 per-image output hashes (little-endian u64 each) — what the GPU tests assert for
+                     the per-batch-launch and the fused forms of the resident stream.
 Fixtures are data (inputs/expected outputs); no reference source is stored.
+
+    python tests/golden/make_golden.py --stream-only     # recompute only the "stream" section (keeps the rest)
 """
 import json
 import os
@@ -35,8 +41,42 @@ def hx(v: int) -> str:
     return f"{v:016x}"
 
 
+def stream_section(n: int = 5000, h: int = 256, w: int = 256, c: int = 3, threads: int = 8) -> dict:
+    """The headline stream through the UNMODIFIED reference kernel, image by image on `threads` host threads."""
+    import threading
+    rlib = O.ref()
+    src = O.lcg_stream(n, h, w, c)
+    out = np.empty_like(src)
+    isz = h * w * c
+
+    def work(b, e):
+        for i in range(b, e):
+            rlib.ref_gaussian_blur(src.ctypes.data + i * isz, out.ctypes.data + i * isz, w, h, c)
+
+    th = [threading.Thread(target=work, args=(n * t // threads, n * (t + 1) // threads)) for t in range(threads)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in (0, 1, 2499, 4999):          # the restatement agrees on a sample
+        assert np.array_equal(out[i], O.blur(src[i], 1)), i
+    per_image = np.array([O.fnv1a64(out[i]) for i in range(n)], dtype="<u8")
+    return {"n": n, "h": h, "w": w, "c": c, "radius": 1, "first_index": 0,
+            "in_fnv": hx(O.fnv1a64(src)), "out_fnv": hx(O.fnv1a64(out)),
+            "per_image_fnv_digest": hx(O.fnv1a64(per_image.view(np.uint8))),
+            "image_fnv": {str(i): hx(int(per_image[i])) for i in (0, 34, 35, 2499, 4969, 4999)}}
+
+
 def main() -> None:
     O.build(ref=True)
+    if "--stream-only" in sys.argv:
+        path = os.path.join(HERE, "blur_golden.json")
+        gold = json.load(open(path))
+        gold["stream"] = stream_section()
+        with open(path, "w") as f:
+            json.dump(gold, f, indent=1)
+        print("stream:", gold["stream"])
+        return
     gold = {"generator": "tests/golden/make_golden.py", "source": "oracle/_ref (unmodified gaussian_kernel.cl)",
             "lcg": {"a": 1664525, "c": 1013904223, "seed": O.LCG_SEED, "byte": "s>>24"},
             "hash": "FNV-1a-64", "k3": [], "literals": [], "a2_split": [], "k5_unpinned": []}
@@ -80,6 +120,8 @@ def main() -> None:
         assert np.array_equal(out, O.blur_f32(img, 2)) and np.array_equal(out, O.np_blur(img, 2))
         gold["k5_unpinned"].append({"h": h, "w": w, "c": c, "out_fnv": hx(O.fnv1a64(out)),
                                     "first": out.reshape(-1)[:8].tolist()})
+
+    gold["stream"] = stream_section()
 
     with open(os.path.join(HERE, "blur_golden.json"), "w") as f:
         json.dump(gold, f, indent=1)

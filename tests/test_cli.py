@@ -90,6 +90,64 @@ def test_gpu_modes_fail_loudly_without_gpu(apps, L, tmp_path):
     assert r.returncode != 0 and "Error: Could not find both CPU and GPU devices" in r.stdout
 
 
+# Column names of the reference's aggregated log table, data/approach2/approach2/per_run.csv:1 (33 columns); --csv writes
+# exactly these, in this order, followed by three MI355X columns.
+REF_PER_RUN_COLUMNS = ("batch_size_file,run,file,mode,gpu_ratio_cfg,cpu_ratio_cfg,images,batches,img_w,img_h,wg_w,wg_h,wall_ms,cpu_images,"
+                       "cpu_total_ms,cpu_in_ms,cpu_kernel_ms,cpu_out_ms,cpu_ms_per_img,gpu_images,gpu_total_ms,gpu_in_ms,gpu_kernel_ms,"
+                       "gpu_out_ms,gpu_ms_per_img,speedup_gpu_vs_cpu,imbalance_pct,bottleneck,bottleneck_delta_ms,mpix_per_sec,img_per_sec,"
+                       "recommended_gpu_ratio,batch_size_log").split(",")
+MI355X_CSV_COLUMNS = ["hbm_gbps", "roofline_frac", "n_gpus"]
+
+
+def read_csv(path):
+    rows = [l.split(",") for l in open(path).read().splitlines()]
+    assert rows[0] == REF_PER_RUN_COLUMNS + MI355X_CSV_COLUMNS
+    assert all(len(r) == len(rows[0]) for r in rows[1:])
+    return [dict(zip(rows[0], r)) for r in rows[1:]]
+
+
+def test_csv_columns_are_the_reference_table_plus_three(apps, tmp_path):
+    ref = "/root/reference/data/approach2/approach2/per_run.csv"
+    if os.path.exists(ref):                       # build container: the constant above IS the reference file's header
+        assert open(ref).readline().strip().split(",") == REF_PER_RUN_COLUMNS
+    assert len(REF_PER_RUN_COLUMNS) == 33
+    het, _ = apps
+    r = run([het, "cpu", "0.5", "35", "--size", "64x48", "--images", "70", "--csv", "run.csv"], tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    row, = read_csv(tmp_path / "run.csv")
+    assert row["mode"] == "cpu" and row["images"] == "70" and row["batches"] == "2" and (row["img_w"], row["img_h"]) == ("64", "48")
+    assert float(row["hbm_gbps"]) == 0.0 and float(row["roofline_frac"]) == 0.0      # no GPU kernel ran in cpu mode
+
+
+@pytest.mark.gpu
+def test_csv_rows_in_gpu_modes(apps, tmp_path):
+    """--csv with a GPU in the loop: the reference's 33 columns + hbm_gbps / roofline_frac / n_gpus, filled from the
+    dispatch timestamps.  gpu mode, both mode, two logical GPUs (MI_BLUR_VIRTUAL_GPUS on a one-GPU box), the resident
+    stream, and split_image_blur append to one file."""
+    het, spl = apps
+    env = dict(os.environ, MI_BLUR_VIRTUAL_GPUS="1")
+
+    def go(cmd, e=None):
+        r = subprocess.run(cmd + ["--csv", "runs.csv"], cwd=tmp_path, capture_output=True, text=True, timeout=600, env=e or os.environ)
+        assert r.returncode == 0, r.stdout + r.stderr
+
+    go([het, "gpu", "1.0", "35", "--size", "256x256", "--images", "700"])
+    go([het, "both", "0.7", "35", "--size", "256x256", "--images", "700"])
+    go([het, "gpu", "1.0", "35", "--size", "256x256", "--images", "700", "--gpus", "2"], env)
+    go([het, "gpu", "1.0", "35", "--size", "256x256", "--images", "5000", "--resident"])
+    go([spl, "0.837", "35", "--size", "320x240", "--images", "140"])
+    rows = read_csv(tmp_path / "runs.csv")
+    assert [r["mode"] for r in rows] == ["gpu", "both", "gpu", "gpu", "split"]
+    assert [r["n_gpus"] for r in rows] == ["1", "1", "2", "1", "1"]
+    for r in rows:
+        assert float(r["hbm_gbps"]) > 0 and 0 < float(r["roofline_frac"]) <= 1, r
+        assert float(r["wall_ms"]) > 0 and float(r["img_per_sec"]) > 0 and float(r["gpu_kernel_ms"]) > 0, r
+        assert abs(float(r["gpu_ratio_cfg"]) + float(r["cpu_ratio_cfg"]) - 1) < 1e-6
+    assert rows[0]["gpu_images"] == "700" and rows[0]["cpu_images"] == "0"
+    assert rows[1]["gpu_images"] == "480" and rows[1]["cpu_images"] == "220"      # 20 x (11 cpu + 24 gpu), heterogeneous_blur.c:449-458
+    assert rows[3]["images"] == "5000" and float(rows[3]["roofline_frac"]) > 0.05   # resident stream: kernel-bound figure
+
+
 @pytest.mark.gpu
 def test_a1_gpu_and_both_modes(apps, O, tmp_path):
     het, _ = apps
@@ -139,6 +197,10 @@ def test_a2_split_host(apps, O, tmp_path):
     # resident row-shard mode on one GPU (no exchange partner: both image edges clamp)
     r = run([spl, "--resident", "--gpus", "1", "--size", "2048x1024", "--iters", "5"], tmp_path)
     assert r.returncode == 0 and "EQUALS the single-device blur" in r.stdout, r.stdout + r.stderr
+    assert "halo_exchange_us" in r.stdout and "band_kernel_us" in r.stdout, r.stdout
+    # BASELINE configs[4] at full size on one GPU: the printed hash is the reference kernel's (tests/golden k3 8192x8192x3)
+    r = run([spl, "--resident", "--gpus", "1", "--size", "8192x8192", "--iters", "5"], tmp_path)
+    assert r.returncode == 0 and "EQUALS the single-device blur (fnv d283787bcc5b6dfd)" in r.stdout, r.stdout + r.stderr
     # iterated blur (output shard feeds the next iteration): 3 successive 3x3 blurs == oracle applied 3 times
     r = run([spl, "--resident", "--iterate", "--gpus", "1", "--size", "320x240", "--iters", "3", "--save", "it3.ppm"], tmp_path)
     assert r.returncode == 0 and "EQUALS the single-device blur" in r.stdout, r.stdout + r.stderr
@@ -148,11 +210,43 @@ def test_a2_split_host(apps, O, tmp_path):
     assert np.array_equal(read_ppm(tmp_path / "it3.ppm"), src)
 
 
-@pytest.mark.gpu
-def test_bench_two_rank_rehearsal(pkg):
-    """bench.py's N>1 control path (rank env, sharding offsets, barrier, max over ranks, rank-0 JSON) on a one-GPU
-    box: two ranks share cuda:0 and use gloo for the barrier (RCCL refuses two ranks on one device)."""
+def _bench_line(r):
     import json
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, printed by rank 0"
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_spawns_its_own_ranks(pkg):
+    """`python bench.py --gpus 2` with NO launcher: the parent starts two ranks itself (fresh children, before any GPU call)
+    and relays rank 0's one JSON line with n_gpus = 2.  Rehearsal on a one-GPU box: both ranks share cuda:0 and use gloo
+    for the barrier (RCCL refuses two ranks on one device).  Without the rehearsal env the same command must FAIL on a
+    one-GPU box — never run one rank and report it as two."""
+    import sys
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(pkg.ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--ramp-seconds", "0.05"]
+    r = subprocess.run(cmd + ["--images", "700"], cwd=pkg.ROOT, env=dict(env, MI_BLUR_BENCH_BACKEND="gloo", MI_BLUR_BENCH_DEVICE="0"),
+                       capture_output=True, text=True, timeout=600)
+    d = _bench_line(r)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d and "extra" not in d
+    assert d["config"]["images_per_gpu_per_step"] == 700 and d["config"]["images_per_step"] == 1400 and d["roofline"]["bound"] == "hbm"
+    # default share at N=2 is 50000 // 2 per GPU (configs[3]); two ranks on one device hold 2 x 9.8 GB
+    r = subprocess.run(cmd, cwd=pkg.ROOT, env=dict(env, MI_BLUR_BENCH_BACKEND="gloo", MI_BLUR_BENCH_DEVICE="0"),
+                       capture_output=True, text=True, timeout=900)
+    d = _bench_line(r)
+    assert d["n_gpus"] == 2 and d["config"]["images_per_gpu_per_step"] == 25000 and "configs[3]" in d["config"]["workload"]
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(cmd, cwd=pkg.ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode != 0 and "only 1 HIP device" in r.stderr and not r.stdout.strip(), r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal_under_launcher(pkg):
+    """The driver's form: ranks created by torch.distributed.run (rank env, sharding offsets, barrier, max over ranks,
+    rank-0 JSON); nothing is spawned by bench.py itself."""
     import socket
     import sys
     with socket.socket() as s:
@@ -161,14 +255,33 @@ def test_bench_two_rank_rehearsal(pkg):
     env = dict(os.environ, MI_BLUR_BENCH_BACKEND="gloo", MI_BLUR_BENCH_DEVICE="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(pkg.ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--images", "700"]
+           "--images", "700", "--ramp-seconds", "0.05"]
     r = subprocess.run(cmd, cwd=pkg.ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, "exactly one JSON line, printed by rank 0"
-    d = json.loads(lines[0])
+    d = _bench_line(r)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d
     assert d["config"]["images_per_gpu_per_step"] == 700 and d["roofline"]["bound"] == "hbm"
+
+
+@pytest.mark.gpu
+def test_bench_default_line_carries_every_single_gpu_config(pkg):
+    """The default N=1 line: configs[1] as `value`, plus configs[2] (hd1080_5x5 with its own frac), configs[4] at N=1
+    (a2_8192_1gpu, whose output hashes like the reference kernel's), the PCIe-inclusive rate at batch 35 and 500, the
+    sustained repeat, roofline and cpu_baseline."""
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(pkg.ROOT, "bench.py"), "--steps", "20", "--warmup", "5"], cwd=pkg.ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    d = _bench_line(r)
+    assert d["n_gpus"] == 1 and d["dtype"] == "u8" and "configs[1]" in d["config"]["workload"] and d["vs_baseline"] is None
+    assert 0 < d["roofline"]["frac"] <= 1 and d["roofline"]["kernel"] == "blur_fused_kernel" and d["roofline"]["launches_timed"] == 20
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["kind"] == "port"
+    assert d["sustained"]["seconds"] >= 1.0 and d["sustained_img_s"] > 0
+    ex = d["extra"]
+    assert set(ex) >= {"hd1080_5x5", "a2_8192_1gpu", "e2e_pcie_inclusive", "one_launch_5000_images"}
+    assert 0 < ex["hd1080_5x5"]["frac"] <= 1 and 0 < ex["a2_8192_1gpu"]["frac"] <= 1
+    assert ex["a2_8192_1gpu"]["out_fnv"] == "d283787bcc5b6dfd"             # tests/golden k3 8192x8192x3 (reference kernel)
+    assert ex["e2e_pcie_inclusive"]["batch_35"]["img_s"] > 0 and ex["e2e_pcie_inclusive"]["batch_500"]["img_s"] > 0
+    assert d["per_batch_launches"]["launches_per_step"] == 143
 
 
 @pytest.mark.gpu

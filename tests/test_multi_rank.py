@@ -102,3 +102,39 @@ def test_bench_json_helpers():
     assert parts[0][0] == 0 and parts[-1][1] == 50000 and all(e - b == 6250 for b, e in parts)
     assert bench.aggregate_max(1.5, None) == 1.5
     assert bench.load_traffic("no-such-workload") is None
+
+
+def test_bench_default_images_follow_the_baseline_configs():
+    """N=1 is configs[1] (5000 images); N>1 shards configs[3]'s 50 000 images, so N=8 is exactly 6250 per GPU."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert [bench.default_images(n) for n in (1, 2, 4, 8)] == [5000, 25000, 12500, 6250]
+    assert bench.default_images(8) * 8 == bench.CONFIG3_IMAGES
+
+
+def _run_bench(args, env_extra=None, drop=()):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK") + tuple(drop)}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT,
+                          capture_output=True, text=True, timeout=600)
+
+
+def test_bench_gpus_n_never_degrades_to_one_rank():
+    """`bench.py --gpus N` must either run N ranks or fail: (a) with fewer than N devices visible and no launcher it
+    exits non-zero naming the shortfall; (b) a launcher that made a different number of ranks is refused; (c) when it
+    spawns the ranks itself and one of them fails, the job fails (here: the children find no GPU) and says which rank."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], drop=("MI_BLUR_BENCH_DEVICE",))
+        assert r.returncode != 0 and "--gpus 2 but only" in r.stderr and not r.stdout.strip(), r.stdout + r.stderr
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "3", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr
+    r = _run_bench(["--gpus", "1", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "2", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+    if not torch.cuda.is_available():
+        # rehearsal env skips the device-count gate, so the parent really spawns 2 children; without a GPU each child
+        # stops at "needs a GPU" and the parent must report the failure instead of printing a line
+        r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"MI_BLUR_BENCH_DEVICE": "0", "MI_BLUR_BENCH_BACKEND": "gloo"})
+        assert r.returncode != 0 and "exited with" in r.stderr and "needs a GPU" in r.stderr, r.stdout + r.stderr
+        assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -183,3 +183,14 @@ def test_layout_restatement(O):
         for radius in (1, 2):
             per_plane = np.stack([O.blur(np.ascontiguousarray(planar[k][:, :, None]), radius)[:, :, 0] for k in range(c)])
             assert np.array_equal(O.planar_to_interleaved(per_plane), O.blur(inter, radius))
+
+
+def test_golden_stream_section_sample(O, golden):
+    """The "stream" fixture (whole 5000-image headline stream through the reference kernel): the oracle reproduces the
+    committed per-image hashes on the sampled indices (the full 983 MB digest is asserted on the GPU, -m gpu)."""
+    e = golden["stream"]
+    assert (e["n"], e["h"], e["w"], e["c"], e["radius"]) == (5000, 256, 256, 3, 1)
+    for k, v in e["image_fnv"].items():
+        img = O.lcg_stream(1, e["h"], e["w"], e["c"], first_index=e["first_index"] + int(k))[0]
+        assert f"{O.fnv1a64(O.blur(img, 1)):016x}" == v, k
+    assert e["image_fnv"]["0"] == [x for x in golden["k3"] if (x["h"], x["w"], x["c"]) == (256, 256, 3)][0]["out_fnv"]
