@@ -54,9 +54,11 @@
 #include <hip/hip_ext.h>
 #include <type_traits>
 #include <limits.h>
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
+#include <algorithm>
 
 namespace mi_blur {
 
@@ -123,6 +125,35 @@ __device__ __forceinline__ uint32_t tap(const uint32_t (&Ew)[8], const uint32_t 
     }
 }
 
+// The same two fields taken straight from the RAW window dwords w[0..7] (row-stream bytes [-8, 24)): bytes q0 and q0+2
+// are at most 8 bytes apart, so one v_perm_b32 over (w[j+1], w[j]) — or a plain AND when they are bytes 0 and 2 of one
+// dword — builds the field pair with no separate even/odd split and no funnel shift.  A row pass needs 24 (5x5) / 18
+// (3x3) distinct pairs against 16 + 14 / 12 + 8 split-then-shift operations.
+template <int K, int PI, int I>
+__device__ __forceinline__ uint32_t tap_raw(const uint32_t (&w)[8])
+{
+    constexpr int q0 = 8 + 4 * I + PI + K;
+    static_assert(q0 >= 0 && q0 + 2 < 32, "tap outside the staged window");
+    constexpr int j = q0 >> 2, m = q0 & 3;
+    if constexpr (m == 0) return w[j] & EVEN_MASK;
+    else if constexpr (m == 1) return __builtin_amdgcn_perm(0u, w[j], 0x0c030c01u);
+    else if constexpr (m == 2) return __builtin_amdgcn_perm(w[j + 1], w[j], 0x0c040c02u);
+    else return __builtin_amdgcn_perm(w[j + 1], w[j], 0x0c050c03u);
+}
+
+template <int C, int R, int PI, int I>
+__device__ __forceinline__ uint32_t hsum_raw(const uint32_t (&w)[8])
+{
+    const uint32_t c = tap_raw<0, PI, I>(w);
+    if constexpr (R == 1) {
+        return (tap_raw<-C, PI, I>(w) + tap_raw<C, PI, I>(w)) + (c << 1);
+    } else {
+        const uint32_t t = tap_raw<-2 * C, PI, I>(w) + tap_raw<2 * C, PI, I>(w);
+        const uint32_t u = tap_raw<-C, PI, I>(w) + tap_raw<C, PI, I>(w);
+        return mad6(c, (u << 2) + t);
+    }
+}
+
 // Horizontal tap sum for the PI-parity bytes of chunk dword I (two 16-bit fields).
 template <int C, int R, int PI, int I>
 __device__ __forceinline__ uint32_t hsum(const uint32_t (&Ew)[8], const uint32_t (&Ow)[8])
@@ -139,7 +170,7 @@ __device__ __forceinline__ uint32_t hsum(const uint32_t (&Ew)[8], const uint32_t
 
 // Horizontal pass of one staged LDS row for this thread's chunk:
 // h[0..3] = even-byte sums of chunk dwords 0..3, h[4..7] = odd-byte sums.
-template <int C, int R>
+template <int C, int R, int X>
 __device__ __forceinline__ void hrow_window(uint32_t (&w)[8], bool any_edge, bool at_start, bool at_end, uint32_t (&h)[8]);
 
 // SHFL = wavefront-shuffle row pass: the 8 bytes either side of the chunk come from the neighbouring lanes'
@@ -147,7 +178,13 @@ __device__ __forceinline__ void hrow_window(uint32_t (&w)[8], bool any_edge, boo
 // adjacent lane (first/last lane of the wave, first/last chunk column of the tile) read them from the LDS halo.
 // !SHFL: every lane reads its 8+16+8 bytes from LDS.  Measured (profiles/): the LDS form is not slower — the
 // two ds_read_b64 it saves cost no VALU slot, the four DPP moves it adds do — so it is the default.
-template <int C, int R, bool SHFL>
+// X = row-pass form: 0 = split every window dword into even/odd fields, then shift (tap); 1 = field pairs straight from the
+// raw window (tap_raw).  Measured (profiles/r02_ab_row_pass.txt): 1 is 1.4 % faster for 5x5 (1129 against 1188 VALU per
+// wave), 0 is the shorter code for 3x3 (748 against 783) — rowpass_default picks accordingly.
+// (Reading the halo bytes as aligned 16-byte LDS reads instead of the two bank-conflicting 8-byte ones was measured too:
+// no change — the LDS pipe is ~20 % busy, its conflicts cost nothing that shows.)
+template <int R> constexpr int rowpass_default = R == 2 ? 1 : 0;
+template <int C, int R, bool SHFL, int X = rowpass_default<R>>
 __device__ __forceinline__ void hrow(const uint8_t *lp, bool any_edge, bool at_start, bool at_end, bool lds_left, bool lds_right,
                                      uint32_t (&h)[8])
 {
@@ -170,11 +207,11 @@ __device__ __forceinline__ void hrow(const uint8_t *lp, bool any_edge, bool at_s
         const uint2 b = *reinterpret_cast<const uint2 *>(lp + 16);
         w[0] = a.x; w[1] = a.y; w[6] = b.x; w[7] = b.y;
     }
-    hrow_window<C, R>(w, any_edge, at_start, at_end, h);
+    hrow_window<C, R, X>(w, any_edge, at_start, at_end, h);
 }
 
 // Same, from a register window w[0..7] = row-stream bytes [-8, 24) around the chunk.
-template <int C, int R>
+template <int C, int R, int X>
 __device__ __forceinline__ void hrow_window(uint32_t (&w)[8], bool any_edge, bool at_start, bool at_end, uint32_t (&h)[8])
 {
     if (any_edge) {   // wave-uniform: some lane's chunk starts or ends the image row
@@ -182,6 +219,13 @@ __device__ __forceinline__ void hrow_window(uint32_t (&w)[8], bool any_edge, boo
         w[0] = at_start ? __builtin_amdgcn_perm(0u, w[2], sel_left(C, 2)) : w[0];
         w[6] = at_end ? __builtin_amdgcn_perm(0u, w[5], sel_right(C, 0)) : w[6];
         w[7] = at_end ? __builtin_amdgcn_perm(0u, w[5], sel_right(C, 1)) : w[7];
+    }
+    if constexpr (X == 1) {
+        h[0] = hsum_raw<C, R, 0, 0>(w); h[1] = hsum_raw<C, R, 0, 1>(w);
+        h[2] = hsum_raw<C, R, 0, 2>(w); h[3] = hsum_raw<C, R, 0, 3>(w);
+        h[4] = hsum_raw<C, R, 1, 0>(w); h[5] = hsum_raw<C, R, 1, 1>(w);
+        h[6] = hsum_raw<C, R, 1, 2>(w); h[7] = hsum_raw<C, R, 1, 3>(w);
+        return;
     }
     uint32_t Ew[8], Ow[8];
 #pragma unroll
@@ -201,7 +245,7 @@ struct TiledParams {
     int ncols, nstrips;               // chunk columns per strip (<= 62), strips per row
     int TH, ntiles_y, ngroups;        // output rows per tile, row tiles per image, row groups per tile
     unsigned nblocks;
-    int xcd;
+    int xcd;                          // blockIdx -> tile map: 0 identity, 1 XCD-contiguous, r >= 2 runs of r tiles dealt to the XCDs in turn
     int debug_copy;                   // ablation only: skip the arithmetic, store the staged centre chunk
     int tail;                         // RAG: bytes of the row's last chunk that exist (1..16); 16 otherwise
 };
@@ -234,6 +278,20 @@ __device__ __forceinline__ unsigned xcd_contiguous(unsigned L, unsigned n)
     const unsigned q = n >> 3, r = n & 7u, x = L & 7u, k = L >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
 }
+// The same idea at a finer grain: runs of `run` consecutive tiles (tiles that share halo rows: an image, a few tile rows)
+// are dealt to the XCDs in turn, so an XCD's tiles still find their neighbours' rows in its own L2 while its stream walks
+// the WHOLE buffer instead of one eighth of it.  A bijection of [0, n): the last n mod 8*run tiles map to themselves.
+__device__ __forceinline__ unsigned xcd_runs(unsigned L, unsigned n, unsigned run)
+{
+    const unsigned span = 8u * run, full = n - n % span;
+    if (L >= full) return L;
+    const unsigned x = L & 7u, k = L >> 3, j = k / run, o = k - j * run;
+    return (j * 8u + x) * run + o;
+}
+__device__ __forceinline__ unsigned xcd_map(unsigned L, unsigned n, int mode)
+{
+    return mode == 0 ? L : mode == 1 ? xcd_contiguous(L, n) : xcd_runs(L, n, (unsigned)mode);
+}
 
 // 16-byte output store that writes through the (per-XCD, mutually non-coherent) L2 to memory: when its vmcnt has
 // drained the bytes are visible device-wide without an L2 write-back fence.  Fused stream only.
@@ -246,7 +304,7 @@ __device__ __forceinline__ void store16_write_through(uint8_t *q, u32x4 v)
 
 // One workgroup's tile (tile number L of the launch).  Threads may return early; the only barrier is after staging.
 // WT: outputs are written through L2 (store16_write_through).
-template <int C, int R, int RPG, bool DMA, bool SHFL, bool RAG, bool WT = false>
+template <int C, int R, int RPG, bool DMA, bool SHFL, bool RAG, bool WT = false, int X = rowpass_default<R>>
 __device__ __forceinline__ void tiled_tile(const TiledParams &p, unsigned L)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -354,11 +412,11 @@ __device__ __forceinline__ void tiled_tile(const TiledParams &p, unsigned L)
     // shuffle row pass: which lanes cannot get a neighbour's bytes from the adjacent lane
     const bool lds_left = (t & 63) == 0 || col == 0, lds_right = (t & 63) == 63 || col == nc - 1;
 #pragma unroll
-    for (int k = 0; k < 2 * R; k++) hrow<C, R, SHFL>(lp + k * lrow, any_edge, at_start, at_end, lds_left, lds_right, hw[k]);
+    for (int k = 0; k < 2 * R; k++) hrow<C, R, SHFL, X>(lp + k * lrow, any_edge, at_start, at_end, lds_left, lds_right, hw[k]);
 
 #pragma unroll
     for (int r = 0; r < RPG; r++) {
-        hrow<C, R, SHFL>(lp + (r + 2 * R) * lrow, any_edge, at_start, at_end, lds_left, lds_right, hw[(r + 2 * R) % WIN]);
+        hrow<C, R, SHFL, X>(lp + (r + 2 * R) * lrow, any_edge, at_start, at_end, lds_left, lds_right, hw[(r + 2 * R) % WIN]);
         uint32_t o[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -392,7 +450,14 @@ __device__ __forceinline__ void tiled_tile(const TiledParams &p, unsigned L)
 template <int C, int R, int RPG, bool DMA, bool SHFL = false, bool RAG = false>
 __global__ __launch_bounds__(256) void blur_tiled_kernel(const TiledParams p)
 {
-    tiled_tile<C, R, RPG, DMA, SHFL, RAG>(p, p.xcd ? xcd_contiguous(blockIdx.x, p.nblocks) : blockIdx.x);
+    tiled_tile<C, R, RPG, DMA, SHFL, RAG>(p, xcd_map(blockIdx.x, p.nblocks, p.xcd));
+}
+
+// the OTHER row-pass form of the aligned LDS-DMA tiled kernel, for A/B runs (mi_blur_set_option("experiment", 1); C = 3 only)
+template <int C, int R, int RPG, int X>
+__global__ __launch_bounds__(256) void blur_tiled_x_kernel(const TiledParams p)
+{
+    tiled_tile<C, R, RPG, true, false, false, false, X>(p, xcd_map(blockIdx.x, p.nblocks, p.xcd));
 }
 
 // Fused stream: ONE dispatch for a whole pass of the resident stream, with the batch kept as the unit of completion.
@@ -414,7 +479,7 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(const TiledParams p, co
     const unsigned b = blockIdx.x / f.tiles_per_batch, base = b * f.tiles_per_batch;
     const unsigned nb = min(f.tiles_per_batch, p.nblocks - base);          // the last batch may be short
     const unsigned w = blockIdx.x - base;
-    tiled_tile<C, R, RPG, true, false, false, true>(p, base + (p.xcd && nb >= 16 ? xcd_contiguous(w, nb) : w));
+    tiled_tile<C, R, RPG, true, false, false, true>(p, base + (nb >= 16 ? xcd_map(w, nb, p.xcd) : w));
     // Outputs were written THROUGH L2 (the XCDs' L2s are not coherent with each other), so once this wave's stores
     // have drained they are in memory.  No device-scope release fence (an L2 write-back per call: 15x the whole pass when
     // every block does one), no returning atomic (its round trip would keep the block's LDS allocated).
@@ -454,6 +519,7 @@ struct StreamParams {
     int BH, nbands;
     unsigned nblocks;
     int xcd;
+    int updown;                       // odd bands march upwards
 };
 
 struct StreamLane { unsigned col, band; long long img; };
@@ -496,6 +562,14 @@ __global__ __launch_bounds__(256) void blur_stream_kernel(const StreamParams p)
 
     const int row0 = p.y0 + (int)me.band * p.BH, row0e = p.y0 + (int)he.band * p.BH;
     const int rows_out = valid ? min(p.BH, p.y1 - row0) : 0;
+    // Marching direction.  The vertical taps are symmetric, so a band can be walked bottom-up with the same arithmetic.
+    // With `updown`, odd bands go up.  The seam between band 2k (down) and band 2k+1 (up) is then read by both at the END of
+    // their march, the seam between band 2k+1 (up) and band 2k+2 (down) by both at the START: the two readers of a seam's
+    // rows come at the same time and the second finds them in L2 instead of fetching them from HBM again.
+    const int bh_me = min(p.BH, p.y1 - row0), bh_e = min(p.BH, p.y1 - row0e);
+    const bool up = p.updown && (me.band & 1u), up_e = p.updown && (he.band & 1u);
+    const int rbase = up ? row0 + bh_me - 1 + R : row0 - R, rstep = up ? -1 : 1;
+    const int rbase_e = up_e ? row0e + bh_e - 1 + R : row0e - R, rstep_e = up_e ? -1 : 1;
     const bool at_start = me.col == 0, at_end = (int)me.col == p.cpr - 1;
     const bool any_edge = __builtin_amdgcn_ballot_w64(at_start || at_end) != 0ull;
     const uint8_t *gsrc = p.in + me.img * p.in_stride + (size_t)me.col * 16u;
@@ -515,11 +589,11 @@ __global__ __launch_bounds__(256) void blur_stream_kernel(const StreamParams p)
 
     auto issue_row = [&](int j) {                    // j-th input row of the band (band row row0 - R + j), clamped to the band
         uint8_t *slot = ring + (j % D) * ROWB;       // wave-uniform
-        const uint8_t *g = gsrc + (size_t)min(max(row0 - R + j, 0), p.H - 1) * (size_t)p.pitch;
+        const uint8_t *g = gsrc + (size_t)min(max(rbase + rstep * j, 0), p.H - 1) * (size_t)p.pitch;
         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)g,
                                          (void __attribute__((address_space(3))) *)(slot + 32), 16, 0, 0);
         if (lane < 2) {
-            const uint8_t *ge = gsrc_e + (size_t)min(max(row0e - R + j, 0), p.H - 1) * (size_t)p.pitch;
+            const uint8_t *ge = gsrc_e + (size_t)min(max(rbase_e + rstep_e * j, 0), p.H - 1) * (size_t)p.pitch;
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)ge,
                                              (void __attribute__((address_space(3))) *)slot, 16, 0, 0);
         }
@@ -549,7 +623,7 @@ __global__ __launch_bounds__(256) void blur_stream_kernel(const StreamParams p)
             uint32_t w[8];
             w[0] = a.x; w[1] = a.y; w[2] = c.x; w[3] = c.y; w[4] = c.z; w[5] = c.w; w[6] = b.x; w[7] = b.y;
             issue_row(j + P);                                // into the slot read two steps ago
-            hrow_window<C, R>(w, any_edge, at_start, at_end, hw[m]);
+            hrow_window<C, R, rowpass_default<R>>(w, any_edge, at_start, at_end, hw[m]);
             const int i = j - 2 * R;                         // output row completed by this input row
             uint32_t o[4];
 #pragma unroll
@@ -572,7 +646,8 @@ __global__ __launch_bounds__(256) void blur_stream_kernel(const StreamParams p)
             }
             u32x4 v; v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
             const bool st = i >= 0 && i < rows_out;          // exactly one store per step, dropped when not wanted
-            __builtin_amdgcn_raw_buffer_store_b128(v, rout, (int)(st ? dst_off + (unsigned)i * (unsigned)p.pitch : OOB), 0, 0);
+            const unsigned orow = (unsigned)(up ? rows_out - 1 - i : i);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rout, (int)(st ? dst_off + orow * (unsigned)p.pitch : OOB), 0, 0);
         }
     }
     wait_vmcnt<0>();                                         // the last prefetches land before the LDS is released
@@ -625,7 +700,7 @@ static std::mutex &tunables_mutex() { static std::mutex m; return m; }
 static Tunables &tunables_storage()
 {
     static Tunables t = [] {
-        Tunables v{1, 0, 1, 0, 0, 0, 0, 1, 1, 0};  // rpg 0 / stream_bh 0 = choose per launch
+        Tunables v{1, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0, 1};  // rpg 0 / stream_bh 0 = choose per launch
         if (const char *e = getenv("MI_BLUR_STAGE")) v.stage_dma = strcmp(e, "reg") != 0;
         if (const char *e = getenv("MI_BLUR_RPG")) { const int r = atoi(e); v.rpg = (r == 4 || r == 8 || r == 16) ? r : 0; }
         if (const char *e = getenv("MI_BLUR_XCD")) v.xcd_remap = atoi(e) != 0;
@@ -671,7 +746,7 @@ static int do_launch(K kernel, dim3 grid, dim3 block, size_t lds, const LaunchDe
 
 template <int C, int R>
 static int launch_tiled_cr(const LaunchDesc &d, const TiledParams &p, dim3 grid, dim3 block, size_t lds,
-                           int rpg, bool dma, bool ragged, bool row_shuffle)
+                           int rpg, bool dma, bool ragged, bool row_shuffle, int experiment)
 {
     if (ragged) {
         if (dma)
@@ -679,6 +754,11 @@ static int launch_tiled_cr(const LaunchDesc &d, const TiledParams &p, dim3 grid,
                             : do_launch(blur_tiled_kernel<C, R, 8, true, false, true>, grid, block, lds, d, p);
         return rpg == 4 ? do_launch(blur_tiled_kernel<C, R, 4, false, false, true>, grid, block, lds, d, p)
                         : do_launch(blur_tiled_kernel<C, R, 8, false, false, true>, grid, block, lds, d, p);
+    }
+    if (experiment && dma && C == 3 && rpg != 16) {
+        constexpr int OTHER = 1 - rowpass_default<R>;
+        return rpg == 4 ? do_launch(blur_tiled_x_kernel<C, R, 4, OTHER>, grid, block, lds, d, p)
+                        : do_launch(blur_tiled_x_kernel<C, R, 8, OTHER>, grid, block, lds, d, p);
     }
     if (row_shuffle && dma) {
         if (rpg == 16) return do_launch(blur_tiled_kernel<C, R, 16, true, true>, grid, block, lds, d, p);
@@ -697,13 +777,13 @@ static int launch_tiled_cr(const LaunchDesc &d, const TiledParams &p, dim3 grid,
 
 template <int R>
 static int launch_tiled_r(const LaunchDesc &d, const TiledParams &p, dim3 grid, dim3 block, size_t lds,
-                          int rpg, bool dma, bool ragged, bool row_shuffle)
+                          int rpg, bool dma, bool ragged, bool row_shuffle, int experiment)
 {
     switch (d.channels) {
-    case 1: return launch_tiled_cr<1, R>(d, p, grid, block, lds, rpg, dma, ragged, row_shuffle);
-    case 2: return launch_tiled_cr<2, R>(d, p, grid, block, lds, rpg, dma, ragged, row_shuffle);
-    case 3: return launch_tiled_cr<3, R>(d, p, grid, block, lds, rpg, dma, ragged, row_shuffle);
-    case 4: return launch_tiled_cr<4, R>(d, p, grid, block, lds, rpg, dma, ragged, row_shuffle);
+    case 1: return launch_tiled_cr<1, R>(d, p, grid, block, lds, rpg, dma, ragged, row_shuffle, experiment);
+    case 2: return launch_tiled_cr<2, R>(d, p, grid, block, lds, rpg, dma, ragged, row_shuffle, experiment);
+    case 3: return launch_tiled_cr<3, R>(d, p, grid, block, lds, rpg, dma, ragged, row_shuffle, experiment);
+    case 4: return launch_tiled_cr<4, R>(d, p, grid, block, lds, rpg, dma, ragged, row_shuffle, experiment);
     }
     return MI_BLUR_ERR_INVALID;
 }
@@ -769,7 +849,17 @@ static int launch_tiled(const LaunchDesc &d, const Tunables &tun, bool ragged = 
     const long long nblocks = (long long)d.n_images * p.ntiles_y * p.nstrips;
     if (nblocks > 0x7fffffffLL) return MI_BLUR_ERR_INVALID;
     p.nblocks = (unsigned)nblocks;
-    p.xcd = tun.xcd_remap && nblocks >= 16;
+    // blockIdx -> tile map.  Rows of one strip (small images): one contiguous eighth of the launch per XCD.  Several strips
+    // per row: runs of a few tile rows dealt to the XCDs in turn — 1-2 % faster there (profiles/r02_xcd_runs.txt): every
+    // XCD then sweeps the whole buffer, and the halo rows a run shares with the next one are served by the memory-side cache.
+    int xmap = 0;
+    if (tun.xcd_remap && nblocks >= 16) {
+        if (tun.xcd_run >= 2) xmap = tun.xcd_run;
+        else if (tun.xcd_run == 1 || p.nstrips == 1) xmap = 1;
+        else xmap = p.nstrips * std::max(1, 24 / p.nstrips);
+        if (xmap >= 2 && (long long)xmap * 8 > nblocks) xmap = 1;
+    }
+    p.xcd = xmap;
     p.debug_copy = tun.debug_copy;
     p.tail = pitch % 16 ? pitch % 16 : 16;
 
@@ -789,8 +879,8 @@ static int launch_tiled(const LaunchDesc &d, const Tunables &tun, bool ragged = 
         p.debug_copy = 0;
         return R == 1 ? launch_fused_r<1>(d, p, f, grid, block, lds, rpg) : launch_fused_r<2>(d, p, f, grid, block, lds, rpg);
     }
-    return R == 1 ? launch_tiled_r<1>(d, p, grid, block, lds, rpg, tun.stage_dma != 0, ragged, tun.row_shuffle != 0)
-                  : launch_tiled_r<2>(d, p, grid, block, lds, rpg, tun.stage_dma != 0, ragged, tun.row_shuffle != 0);
+    return R == 1 ? launch_tiled_r<1>(d, p, grid, block, lds, rpg, tun.stage_dma != 0, ragged, tun.row_shuffle != 0, tun.experiment)
+                  : launch_tiled_r<2>(d, p, grid, block, lds, rpg, tun.stage_dma != 0, ragged, tun.row_shuffle != 0, tun.experiment);
 }
 
 int launch_fused(const LaunchDesc &d, const FusedDesc &f)
@@ -811,11 +901,25 @@ static int launch_stream(const LaunchDesc &d, const Tunables &tun)
     p.in_stride = (long long)d.band_rows * pitch;
     p.out_stride = (long long)rows * pitch;
     p.pitch = pitch; p.cpr = cpr; p.H = d.band_rows; p.y0 = d.y0; p.y1 = d.y1;
-    // Band height: tall bands re-read fewer halo rows (2R/BH), short ones give small grids enough waves.
+    // Band height: tall bands re-read fewer halo rows (2R/BH), short ones give small grids enough waves.  A wave lives as
+    // long as its band is tall and ~16 waves fit a CU, so the launch runs in "rounds" of resident waves: pick the band
+    // count whose last round is fullest (a launch of 1.5 rounds runs its second half at half occupancy), weighted by the
+    // halo re-read overhead BH / (BH + 2R).
     int BH = tun.stream_bh;
     if (BH <= 0) {
+        const double slots = 256.0 * 16.0;
+        double best = -1.0;
         BH = 64;
-        while (BH > 8 && (long long)d.n_images * ((rows + BH - 1) / BH) * cpr / 64 < 256 * 16) BH >>= 1;
+        for (int nb = (rows + 127) / 128; nb <= (rows + 23) / 24; nb++) {
+            const int bh = (rows + nb - 1) / nb;
+            const double waves = (double)d.n_images * nb * cpr / 64.0;
+            const double rounds = waves / slots;
+            const double full = rounds >= 1.0 ? rounds / ceil(rounds - 1e-9) : rounds;
+            const double score = full * bh / (bh + 2.0 * d.radius);
+            if (score > best + 1e-9) { best = score; BH = bh; }
+        }
+        // small grids (well under one round of resident waves): shorter bands, more waves
+        while (BH > 8 && (long long)d.n_images * ((rows + BH - 1) / BH) * cpr / 64 < 256 * 8) BH >>= 1;
     }
     if (BH > rows) BH = rows;
     p.BH = BH;
@@ -826,6 +930,7 @@ static int launch_stream(const LaunchDesc &d, const Tunables &tun)
     const long long nblocks = (p.total + 255) / 256;
     p.nblocks = (unsigned)nblocks;
     p.xcd = tun.xcd_remap && nblocks >= 16;
+    p.updown = tun.stream_updown;
     const dim3 grid((unsigned)nblocks), block(256);
     const size_t lds = 4 * STREAM_D * STREAM_ROWB;
     switch (d.channels * 10 + d.radius) {

@@ -51,6 +51,10 @@ bool tiled_eligible(const void *in, const void *out, int width, int channels);
 struct Tunables {
     int stage_dma; int rpg; int xcd_remap; int debug_copy; int row_shuffle; int prefer_stream; int stream_bh; int zero_copy; int ragged;
     int fused_release;   // fused stream: 1 = the per-block completion add is release-ordered at agent scope (architectural; slow)
+    int experiment;      // 1 = the tiled kernel's OTHER row-pass form (A/B runs; C = 3 only)
+    int xcd_run;         // tiled kernel's blockIdx -> tile map: 0 = chosen per launch, 1 = one contiguous eighth per XCD,
+                         // r >= 2 = runs of r tiles dealt to the XCDs in turn
+    int stream_updown;   // streaming variant: 1 (default) = odd bands march upwards, so both readers of a band seam come at the same time
 };
 Tunables tunables();
 void set_tunables(const Tunables &t);

@@ -88,6 +88,9 @@ extern "C" int mi_blur_set_option(const char *key, int value)
     else if (!strcmp(key, "ragged_tiled")) t.ragged = value != 0;
     else if (!strcmp(key, "stream_band_rows")) { if (value < 0 || value > 4096) return MI_BLUR_ERR_INVALID; t.stream_bh = value; }
     else if (!strcmp(key, "fused_release")) t.fused_release = value != 0;
+    else if (!strcmp(key, "experiment")) t.experiment = value != 0;
+    else if (!strcmp(key, "stream_updown")) t.stream_updown = value != 0;
+    else if (!strcmp(key, "xcd_run")) { if (value < 0 || value > (1 << 20)) return MI_BLUR_ERR_INVALID; t.xcd_run = value; }
     else return MI_BLUR_ERR_INVALID;
     set_tunables(t);
     return MI_BLUR_OK;

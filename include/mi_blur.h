@@ -66,7 +66,13 @@ int mi_blur_version(void);
  * copy of; a launch racing with the call uses the old set or the new one, never a mix.
  *   "stage_dma"        1 = stage LDS tiles with global_load_lds (default), 0 = through VGPRs
  *   "rows_per_thread"  0 (default: chosen per launch from the grid size) | 4 | 8 | 16 output rows per thread
- *   "xcd_remap"        1 = XCD-contiguous blockIdx->tile map (default), 0 = identity
+ *   "xcd_remap"        1 = XCD-aware blockIdx->tile map (default), 0 = identity
+ *   "xcd_run"          which XCD-aware map: 0 (default) chosen per launch | 1 one contiguous eighth of the tiles per XCD |
+ *                      r >= 2 runs of r consecutive tiles dealt to the XCDs in turn
+ *   "experiment"       1 = the tiled kernel's other row-pass form (field pairs straight from the raw window for 3x3,
+ *                      split-then-shift for 5x5; C = 3 only) — A/B runs
+ *   "stream_updown"    streaming variant: 1 (default) = odd bands march upwards (both readers of a band seam come at the
+ *                      same time: fewer HBM re-reads), 0 = every band downwards
  *   "row_shuffle"      1 = x-neighbour bytes by DPP wave shifts (LDS only at wave/tile edges), 0 = from LDS (default)
  *   "prefer_stream"    1 = AUTO picks the streaming variant instead of the tiled one (default 0)
  *   "stream_band_rows" streaming variant: output rows per wave (0 = chosen per launch)

@@ -50,6 +50,9 @@ def reset_opts(L):
     L.mi_blur_set_option(b"ragged_tiled", 1)
     L.mi_blur_set_option(b"rows_per_thread", 0)
     L.mi_blur_set_option(b"xcd_remap", 1)
+    L.mi_blur_set_option(b"experiment", 0)
+    L.mi_blur_set_option(b"stream_updown", 1)
+    L.mi_blur_set_option(b"xcd_run", 0)
 
 
 def want_batch(O, host, radius):
@@ -112,10 +115,52 @@ def test_stream_kernel_bit_exact(pkg, L, O, torch_cuda, h, w, c, radius):
     try:
         for host in adversarial(O, h, w, c, n, h * 11 + w):
             want = want_batch(O, host, radius)
-            for opts in ({"stream_band_rows": 0, "xcd_remap": 1}, {"stream_band_rows": 5, "xcd_remap": 0},
-                         {"stream_band_rows": 64, "xcd_remap": 1}):
+            for opts in ({"stream_band_rows": 0, "xcd_remap": 1}, {"stream_band_rows": 5, "xcd_remap": 0, "stream_updown": 0},
+                         {"stream_band_rows": 64, "xcd_remap": 1, "stream_updown": 1}):
                 got = gpu_blur(pkg, L, torch_cuda, host, radius, pkg.VARIANT_STREAM, opts=opts)
                 assert np.array_equal(got, want), f"{(got != want).sum()} bytes differ, opts={opts}"
+    finally:
+        reset_opts(L)
+
+
+@pytest.mark.parametrize("radius", [1, 2])
+def test_tiled_experiment_variants_bit_exact(pkg, L, O, torch_cuda, radius):
+    """Both row-pass forms of the tiled kernel (field pairs straight from the raw window by v_perm / split-then-shift) and
+    the blockIdx -> tile maps (per-launch choice, contiguous eighths, runs of r tiles dealt to the XCDs): same bytes as the
+    oracle on C = 3 shapes incl. row edges, several strips, short tiles, tile counts that are not multiples of 8 x run."""
+    try:
+        for (h, w, c) in [(16, 16, 3), (9, 48, 3), (33, 80, 3), (240, 320, 3), (256, 256, 3), (47, 1360, 3), (70, 1920, 3), (3, 21856, 3)]:
+            for host in adversarial(O, h, w, c, 2, h * 5 + w):
+                want = want_batch(O, host, radius)
+                for x in (0, 1):
+                    for rpt, run in ((4, 0), (8, 1), (8, 3), (4, 16)):
+                        got = gpu_blur(pkg, L, torch_cuda, host, radius, pkg.VARIANT_TILED,
+                                       opts={"experiment": x, "rows_per_thread": rpt, "xcd_run": run})
+                        assert np.array_equal(got, want), f"{(got != want).sum()} bytes differ, experiment={x} rpt={rpt} run={run} {(h, w, c)}"
+    finally:
+        reset_opts(L)
+
+
+@pytest.mark.parametrize("radius", [1, 2])
+def test_stream_kernel_updown_bit_exact(pkg, L, O, torch_cuda, radius):
+    """Streaming variant with odd bands marching upwards (stream_updown): bit-exact for band heights that do and do not
+    divide the image, one band, short last bands, bands (Approach-2 clamp at the band's own edges)."""
+    try:
+        for (h, w, c) in [(16, 16, 3), (33, 80, 3), (240, 320, 3), (256, 256, 3), (47, 1360, 3), (131, 112, 1), (100, 16, 4), (1080, 1920, 3)]:
+            host = O.lcg_stream(2, h, w, c) if h < 1000 else O.lcg_stream(1, h, w, c)
+            want = want_batch(O, host, radius)
+            for bh in (0, 5, 7, 64, 100):
+                got = gpu_blur(pkg, L, torch_cuda, host, radius, pkg.VARIANT_STREAM, opts={"stream_updown": 1, "stream_band_rows": bh})
+                assert np.array_equal(got, want), f"{(got != want).sum()} bytes differ, band rows {bh} {(h, w, c)}"
+        img = O.lcg_image(240, 320, 3)
+        whole = O.blur(img, radius)
+        parts = []
+        for g in range(3):
+            b = pkg.band_of(240, radius, g, 3)
+            band = np.ascontiguousarray(img[b["row_begin"] - b["halo_top"]: b["row_end"] + b["halo_bottom"]])[None]
+            parts.append(gpu_blur(pkg, L, torch_cuda, band, radius, pkg.VARIANT_STREAM, y0=b["halo_top"],
+                                  y1=b["halo_top"] + b["row_end"] - b["row_begin"], opts={"stream_updown": 1, "stream_band_rows": 13})[0])
+        assert np.array_equal(np.concatenate(parts), whole)
     finally:
         reset_opts(L)
 

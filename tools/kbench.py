@@ -22,6 +22,8 @@ SHAPES = {
     "hd5": (1080, 1920, 3, 2, 64, 64, 64),
     "hd3": (1080, 1920, 3, 1, 64, 64, 64),
     "big": (8192, 8192, 3, 1, 2, 2, 1),
+    "big1": (8192, 8192, 3, 1, 1, 1, 1),          # the a2 bench shape: one image per launch
+    "hd5x": (1080, 1920, 3, 2, 128, 128, 128),    # same frames, twice the pool
 }
 
 
@@ -30,6 +32,9 @@ def main():
     ap.add_argument("--shape", default="a1,a1one,hd5")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--streams", type=int, default=1)
+    ap.add_argument("--burst", type=int, default=1,
+                    help="launches issued back to back per measurement (1 = isolated launches; 100+ = the sustained regime "
+                         "bench.py measures, where the clock settles under load)")
     ap.add_argument("--opts", default="stage_dma=0,1;rows_per_thread=8,16;xcd_remap=1")
     args = ap.parse_args()
     import torch  # noqa: F401  (before the library: one HIP runtime)
@@ -52,7 +57,8 @@ def main():
                 for k, v in zip(keys, cb):
                     pkg.check(L.mi_blur_set_option(k.encode(), v))
                 ctx.reset_timing()
-                ctx.resident_run(per_pass, batch, timed=True)
+                for _ in range(args.burst):
+                    ctx.resident_run(per_pass, batch, timed=True)
                 tm = ctx.sync()
                 if rep:
                     res[cb].append((tm["kernel_ms"] * 1e3 / tm["launches"], tm["bytes_alg"] / tm["launches"]))
