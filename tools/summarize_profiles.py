@@ -87,6 +87,23 @@ def main():
     ex = os.path.join(src, "bench_a1_extra.json")
     if os.path.exists(ex):
         shutil.copy(ex, os.path.join(dst, f"{tag}_a1_extra_bench.json"))
+    # SQ / LDS / TCC counter passes (pmc_<workload>_<group>): mean per dispatch, per kernel and grid size
+    out = [f"rocprofv3 --pmc passes of `python bench.py [--workload hd5] --no-extra --steps 3 --warmup 1`, {tag}: mean per dispatch",
+           "(SQ_* cycle counters are in quad-cycles summed over the chip; FETCH/TCC per MI355X_MICROARCH.md)", ""]
+    for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+        if not os.path.isdir(d):
+            continue
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in rows(os.path.join(d, "*", "*_counter_collection.csv")):
+            if "blur_" not in r["Kernel_Name"]:
+                continue
+            key = (r["Kernel_Name"].split("(")[0].replace("void mi_blur::", "")[:48], r["Grid_Size"])
+            acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for (k, g), cs in sorted(acc.items()):
+            n = max(len(v) for v in cs.values())
+            out.append(f"{os.path.basename(d):12s} {k:48s} grid {g:>9s} x{n:<3d} " + "  ".join(f"{c}={sum(v) / len(v):.0f}" for c, v in sorted(cs.items())))
+    if len(out) > 3:
+        open(os.path.join(dst, f"{tag}_pmc_counters.txt"), "w").write("\n".join(out) + "\n")
     open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
     json.dump(traffic, open(traffic_path, "w"), indent=1)
     print("\n".join(lines))
