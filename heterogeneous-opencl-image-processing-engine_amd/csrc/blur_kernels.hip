@@ -849,14 +849,13 @@ static int launch_tiled(const LaunchDesc &d, const Tunables &tun, bool ragged = 
     const long long nblocks = (long long)d.n_images * p.ntiles_y * p.nstrips;
     if (nblocks > 0x7fffffffLL) return MI_BLUR_ERR_INVALID;
     p.nblocks = (unsigned)nblocks;
-    // blockIdx -> tile map.  Rows of one strip (small images): one contiguous eighth of the launch per XCD.  Several strips
-    // per row: runs of a few tile rows dealt to the XCDs in turn — 1-2 % faster there (profiles/r02_xcd_runs.txt): every
-    // XCD then sweeps the whole buffer, and the halo rows a run shares with the next one are served by the memory-side cache.
+    // blockIdx -> tile map: one contiguous eighth of the launch per XCD (tile-edge halo rows are then hits in that XCD's
+    // L2 and HBM traffic stays at 1.00x the algorithmic bytes).  Runs of r tiles dealt to the XCDs in turn ("xcd_run" r)
+    // were measured as well (profiles/r02_xcd_runs.txt): +-2 % either way depending on where the buffers happen to lie,
+    // and +0.4..3 % HBM fetch for the seams that cross XCDs — not the default.
     int xmap = 0;
     if (tun.xcd_remap && nblocks >= 16) {
-        if (tun.xcd_run >= 2) xmap = tun.xcd_run;
-        else if (tun.xcd_run == 1 || p.nstrips == 1) xmap = 1;
-        else xmap = p.nstrips * std::max(1, 24 / p.nstrips);
+        xmap = tun.xcd_run >= 2 ? tun.xcd_run : 1;
         if (xmap >= 2 && (long long)xmap * 8 > nblocks) xmap = 1;
     }
     p.xcd = xmap;

@@ -52,7 +52,7 @@ struct Tunables {
     int stage_dma; int rpg; int xcd_remap; int debug_copy; int row_shuffle; int prefer_stream; int stream_bh; int zero_copy; int ragged;
     int fused_release;   // fused stream: 1 = the per-block completion add is release-ordered at agent scope (architectural; slow)
     int experiment;      // 1 = the tiled kernel's OTHER row-pass form (A/B runs; C = 3 only)
-    int xcd_run;         // tiled kernel's blockIdx -> tile map: 0 = chosen per launch, 1 = one contiguous eighth per XCD,
+    int xcd_run;         // tiled kernel's blockIdx -> tile map: 0/1 = one contiguous eighth of the launch per XCD (default),
                          // r >= 2 = runs of r tiles dealt to the XCDs in turn
     int stream_updown;   // streaming variant: 1 (default) = odd bands march upwards, so both readers of a band seam come at the same time
 };

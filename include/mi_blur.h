@@ -67,7 +67,7 @@ int mi_blur_version(void);
  *   "stage_dma"        1 = stage LDS tiles with global_load_lds (default), 0 = through VGPRs
  *   "rows_per_thread"  0 (default: chosen per launch from the grid size) | 4 | 8 | 16 output rows per thread
  *   "xcd_remap"        1 = XCD-aware blockIdx->tile map (default), 0 = identity
- *   "xcd_run"          which XCD-aware map: 0 (default) chosen per launch | 1 one contiguous eighth of the tiles per XCD |
+ *   "xcd_run"          which XCD-aware map: 0 | 1 (default) one contiguous eighth of the launch's tiles per XCD |
  *                      r >= 2 runs of r consecutive tiles dealt to the XCDs in turn
  *   "experiment"       1 = the tiled kernel's other row-pass form (field pairs straight from the raw window for 3x3,
  *                      split-then-shift for 5x5; C = 3 only) — A/B runs

@@ -263,6 +263,24 @@ def test_bench_two_rank_rehearsal_under_launcher(pkg):
 
 
 @pytest.mark.gpu
+def test_bench_a2_two_rank_rehearsal(pkg):
+    """`bench.py --workload a2 --gpus 2` (BASELINE configs[4] shape of work) spawning its own ranks on a one-GPU box: the
+    row split (4096 rows per rank), the timed loop, the per-step decomposition and the overlapped three-launch step all
+    run; only the RCCL exchange itself is left out (two ranks cannot share a device), and the line says so."""
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MI_BLUR_BENCH_BACKEND="gloo", MI_BLUR_BENCH_DEVICE="0")
+    r = subprocess.run([sys.executable, os.path.join(pkg.ROOT, "bench.py"), "--workload", "a2", "--gpus", "2", "--steps", "10", "--warmup", "2"],
+                       cwd=pkg.ROOT, env=env, capture_output=True, text=True, timeout=600)
+    d = _bench_line(r)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["rows_per_gpu"] == 4096 and d["config"]["halo_bytes_per_neighbour"] == 8192 * 3 and "rehearsal" in d["config"]
+    dec = d["config"]["step_decomposition"]
+    assert dec["band_kernel_us"] > 0 and dec["halo_exchange_us"] >= 0 and dec["step_us_plain"] > 0 and dec["step_us_overlapped"] > 0
+    assert 0 < dec["band_kernel_frac"] <= 1 and dec["band_kernel_us_max_over_ranks"] >= dec["band_kernel_us"] - 1e-6
+
+
+@pytest.mark.gpu
 def test_bench_default_line_carries_every_single_gpu_config(pkg):
     """The default N=1 line: configs[1] as `value`, plus configs[2] (hd1080_5x5 with its own frac), configs[4] at N=1
     (a2_8192_1gpu, whose output hashes like the reference kernel's), the PCIe-inclusive rate at batch 35 and 500, the
