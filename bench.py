@@ -610,6 +610,13 @@ def main() -> None:
             exchange(stream)
             blur_rows(ht, ht + owned, 0)
 
+        # untimed ramp past the ~40 ms clock ramp that follows any idle gap.  A FIXED step count, the same on every rank:
+        # each step holds a send/recv pair, so ranks must not decide by their own clocks how many to run.
+        ramp_steps = int(args.ramp_seconds * 1e6 / 100.0)
+        for i in range(ramp_steps):
+            step()
+            if i % 64 == 63:
+                torch.cuda.synchronize()
         for _ in range(W):
             step()
         barrier_sync()
@@ -684,7 +691,7 @@ def main() -> None:
         if not fake_exchange:
             L.mi_blur_comm_destroy(comm)
         config = {"workload": f"one 8192x8192x3 image per step, 3x3, row-split over {world} GPU(s), RCCL halo exchange [BASELINE configs[4]]",
-                  "rows_per_gpu": owned, "halo_bytes_per_neighbour": radius * pitch, "step_decomposition": decomp}
+                  "rows_per_gpu": owned, "halo_bytes_per_neighbour": radius * pitch, "ramp_steps": ramp_steps, "step_decomposition": decomp}
         if fake_exchange:
             config["rehearsal"] = "halo exchange left out (two ranks share one device); control path only"
         base_shape = (H, Wd, c, radius)
