@@ -356,21 +356,22 @@ def main() -> None:
                 "img_s": round(steps / wall, 1), "out_fnv": fnv}
 
     def point_e2e(w, h, c, radius, nb, nbatches) -> dict:
-        """Host buffers in -> host buffers out (zero-copy submits over PCIe), 3 rotating pinned buffer pairs."""
-        e2e = pkg.Context(local_rank, w, h, c, radius, max_batch=nb, n_slots=3)
+        """Host buffers in -> host buffers out (zero-copy submits over PCIe), 4 rotating pinned buffer pairs."""
+        NS = 4
+        e2e = pkg.Context(local_rank, w, h, c, radius, max_batch=nb, n_slots=NS)
         nbytes = nb * h * w * c
-        bufs = [(L.mi_blur_host_alloc(nbytes), L.mi_blur_host_alloc(nbytes)) for _ in range(3)]
+        bufs = [(L.mi_blur_host_alloc(nbytes), L.mi_blur_host_alloc(nbytes)) for _ in range(NS)]
         for (pi, _po) in bufs:
             L.mi_blur_fill_synthetic(pi, w, h, c, 0, nb, 4)
-        for i in range(6):
-            e2e.submit(bufs[i % 3][0], bufs[i % 3][1], nb)
+        for i in range(2 * NS):
+            e2e.submit(bufs[i % NS][0], bufs[i % NS][1], nb)
         e2e.sync(); e2e.reset_timing()
         t0e = time.perf_counter()
         for i in range(nbatches):
-            e2e.submit(bufs[i % 3][0], bufs[i % 3][1], nb)
+            e2e.submit(bufs[i % NS][0], bufs[i % NS][1], nb)
         te = e2e.sync()
         dte = time.perf_counter() - t0e
-        res = {"img_s": round(nbatches * nb / dte, 0), "batch": nb, "batches": nbatches, "slots": 3,
+        res = {"img_s": round(nbatches * nb / dte, 0), "batch": nb, "batches": nbatches, "slots": NS,
                "zero_copy_submits": int(L.mi_blur_zero_copy_launches(e2e.h)),
                "pcie_gbs_each_way": round(nbatches * nbytes / dte / 1e9, 1),
                "h2d_ms": round(te["h2d_ms"], 2), "kernel_ms": round(te["kernel_ms"], 2), "d2h_ms": round(te["d2h_ms"], 2)}

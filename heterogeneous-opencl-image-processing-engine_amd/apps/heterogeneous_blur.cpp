@@ -102,7 +102,10 @@ int main(int argc, char **argv)
     // --resident: launches alternate over the context's streams so the ~4 us per-dispatch floors overlap; 4 streams
     // (one per hardware queue) measured best, and only every 16th dispatch carries timestamps (a timestamped launch
     // costs the host ~3x an ordinary one) — the kernel bucket is scaled up from that sample.
-    const int nslots = (opt.resident && !opt.slots_given) ? 4 : opt.slots;
+    // GPU-only mode from host buffers: 4 rotating buffer sets, so up to 4 zero-copy launches (each capped to a few dozen
+    // workgroups, library default) overlap and keep both directions of the host link busy: 173-180 k img/s at batch 35
+    // against 141-146 k with 2 sets (profiles/r02_e2e.txt).  With CPU threads in the loop (both) 2 sets stay best.
+    const int nslots = opt.slots_given ? opt.slots : ((opt.resident || mode == 2) ? 4 : opt.slots);
     const int resident_timed_every = 16;
     Dev cpu;
     std::vector<Dev> gpus(G);

@@ -453,6 +453,20 @@ __global__ __launch_bounds__(256) void blur_tiled_kernel(const TiledParams p)
     tiled_tile<C, R, RPG, DMA, SHFL, RAG>(p, xcd_map(blockIdx.x, p.nblocks, p.xcd));
 }
 
+// Capped-grid form: at most `gridDim.x` workgroups walk the launch's tiles (block b takes tiles b, b + G, b + 2G ...).
+// For launches whose buffers are PINNED HOST memory (zero-copy submits): the host link needs only ~100 KB in flight to
+// run at full rate, and a launch that puts every tile on the chip at once does all of its reads and then all of its
+// writes — half duplex.  With a few hundred resident workgroups each on its own read -> compute -> write cycle the two
+// directions of the link stay busy together.
+template <int C, int R, int RPG>
+__global__ __launch_bounds__(256) void blur_tiled_loop_kernel(const TiledParams p)
+{
+    for (unsigned L = blockIdx.x; L < p.nblocks; L += gridDim.x) {
+        tiled_tile<C, R, RPG, true, false, false>(p, L);
+        __syncthreads();                      // the next tile is staged into the same LDS
+    }
+}
+
 // the OTHER row-pass form of the aligned LDS-DMA tiled kernel, for A/B runs (mi_blur_set_option("experiment", 1); C = 3 only)
 template <int C, int R, int RPG, int X>
 __global__ __launch_bounds__(256) void blur_tiled_x_kernel(const TiledParams p)
@@ -700,7 +714,7 @@ static std::mutex &tunables_mutex() { static std::mutex m; return m; }
 static Tunables &tunables_storage()
 {
     static Tunables t = [] {
-        Tunables v{1, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0, 1};  // rpg 0 / stream_bh 0 = choose per launch
+        Tunables v{1, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0, 4, 24, 1};  // rpg 0 / stream_bh 0 = choose per launch
         if (const char *e = getenv("MI_BLUR_STAGE")) v.stage_dma = strcmp(e, "reg") != 0;
         if (const char *e = getenv("MI_BLUR_RPG")) { const int r = atoi(e); v.rpg = (r == 4 || r == 8 || r == 16) ? r : 0; }
         if (const char *e = getenv("MI_BLUR_XCD")) v.xcd_remap = atoi(e) != 0;
@@ -754,6 +768,11 @@ static int launch_tiled_cr(const LaunchDesc &d, const TiledParams &p, dim3 grid,
                             : do_launch(blur_tiled_kernel<C, R, 8, true, false, true>, grid, block, lds, d, p);
         return rpg == 4 ? do_launch(blur_tiled_kernel<C, R, 4, false, false, true>, grid, block, lds, d, p)
                         : do_launch(blur_tiled_kernel<C, R, 8, false, false, true>, grid, block, lds, d, p);
+    }
+    if (d.max_blocks > 0 && dma && rpg != 16 && grid.x > (unsigned)d.max_blocks) {
+        const dim3 capped((unsigned)d.max_blocks);
+        return rpg == 4 ? do_launch(blur_tiled_loop_kernel<C, R, 4>, capped, block, lds, d, p)
+                        : do_launch(blur_tiled_loop_kernel<C, R, 8>, capped, block, lds, d, p);
     }
     if (experiment && dma && C == 3 && rpg != 16) {
         constexpr int OTHER = 1 - rowpass_default<R>;

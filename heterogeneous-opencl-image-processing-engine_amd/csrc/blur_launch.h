@@ -14,6 +14,7 @@ struct LaunchDesc {
     int y0, y1;             // output rows [y0,y1) of each band
     long long in_stride, out_stride;  // bytes between consecutive bands / output blocks; 0 = laid end to end.
                             // Non-dense strides are taken by the tiled kernel only (multiples of 16).
+    int max_blocks;         // > 0: cap the grid of the aligned tiled kernel; its workgroups then loop over the tiles (zero-copy submits)
     int variant;            // mi_blur_variant
     hipStream_t stream;
     hipEvent_t start, stop; // optional: dispatch start/stop timestamps (hipExtLaunchKernel)
@@ -54,6 +55,8 @@ struct Tunables {
     int experiment;      // 1 = the tiled kernel's OTHER row-pass form (A/B runs; C = 3 only)
     int xcd_run;         // tiled kernel's blockIdx -> tile map: 0/1 = one contiguous eighth of the launch per XCD (default),
                          // r >= 2 = runs of r tiles dealt to the XCDs in turn
+    int zero_copy_streams;   // streams the zero-copy submits of a context alternate over (1 = one in-order stream)
+    int zero_copy_blocks;    // zero-copy submits: cap on resident workgroups (0 = no cap: one workgroup per tile)
     int stream_updown;   // streaming variant: 1 (default) = odd bands march upwards, so both readers of a band seam come at the same time
 };
 Tunables tunables();

@@ -90,6 +90,8 @@ extern "C" int mi_blur_set_option(const char *key, int value)
     else if (!strcmp(key, "fused_release")) t.fused_release = value != 0;
     else if (!strcmp(key, "experiment")) t.experiment = value != 0;
     else if (!strcmp(key, "stream_updown")) t.stream_updown = value != 0;
+    else if (!strcmp(key, "zero_copy_streams")) { if (value < 1 || value > 8) return MI_BLUR_ERR_INVALID; t.zero_copy_streams = value; }
+    else if (!strcmp(key, "zero_copy_blocks")) { if (value < 0 || value > (1 << 20)) return MI_BLUR_ERR_INVALID; t.zero_copy_blocks = value; }
     else if (!strcmp(key, "xcd_run")) { if (value < 0 || value > (1 << 20)) return MI_BLUR_ERR_INVALID; t.xcd_run = value; }
     else return MI_BLUR_ERR_INVALID;
     set_tunables(t);
@@ -433,7 +435,9 @@ static int submit_common(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_o
             if (zin && zout && (dense || (tiled_eligible(zin, zout, c->W, c->C) && in_stride % 16 == 0 && out_stride % 16 == 0))) {
                 s.out_staged = false; s.user_out = host_out; s.out_bytes = out_bytes; s.out_band = band_out; s.out_stride = out_stride;
                 s.out_n = n_images;
-                const hipStream_t zs = c->slots[0].stream;     // all zero-copy launches of a context: one in-order stream
+                // all zero-copy launches of a context share one in-order stream, unless "zero_copy_streams" says 2
+                const int zn = std::max(1, std::min(tunables().zero_copy_streams, (int)c->slots.size()));
+                const hipStream_t zs = c->slots[(c->zero_copy_launches % (uint64_t)zn)].stream;
                 // one dispatch packet, nothing else: the kernel's own stop event doubles as the completion event (every
                 // extra hipEventRecord is a barrier packet between two kernels)
                 LaunchDesc d{};
@@ -441,6 +445,7 @@ static int submit_common(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_o
                 d.radius = c->R; d.n_images = n_images; d.y0 = y0; d.y1 = y1; d.variant = MI_BLUR_VARIANT_AUTO;
                 d.in_stride = (long long)in_stride; d.out_stride = (long long)out_stride;
                 d.stream = zs; d.start = s.ks; d.stop = s.ke;
+                d.max_blocks = tunables().zero_copy_blocks;
                 rc = launch(d);
                 if (rc) return rc;
                 s.zero_copy = true;                            // only now: a failed launch leaves the slot idle and staged

@@ -80,6 +80,12 @@ int mi_blur_version(void);
  *                      tiled kernel; 0 = they take the generic one-byte-per-thread kernel
  *   "zero_copy"        1 (default) = submits whose input AND output are pinned host memory run the kernel on the
  *                      caller's buffers in place (no staging copies); 0 = always H2D -> kernel -> D2H
+ *   "zero_copy_streams" 4 (default): zero-copy submits of a context alternate over this many of its streams (at most n_slots)
+ *   "zero_copy_blocks"  24 (default): zero-copy launches of the aligned tiled kernel keep at most this many workgroups
+ *                      resident, each looping over tiles (0 = one workgroup per tile).  The host link needs ~100 KB in
+ *                      flight; a launch that puts every tile on the chip at once reads everything, then writes
+ *                      everything (half duplex).  4 x 24 workgroups, each on its own read/compute/write cycle, keep both
+ *                      directions busy: +10-18 % images/s end to end (profiles/r02_e2e.txt)
  *   "fused_release"    0 (default) | 1: how a block of the fused stream publishes "my outputs are in memory" — see
  *                      mi_blur_resident_run_fused */
 int mi_blur_set_option(const char *key, int value);

@@ -350,6 +350,40 @@ def test_context_submit_pageable_and_pinned(pkg, L, O, torch_cuda):
         assert np.array_equal(np.concatenate([top, bot]), want[0])
 
 
+@pytest.mark.parametrize("radius", [1, 2])
+def test_zero_copy_capped_grid_and_streams(pkg, L, O, torch_cuda, radius):
+    """Zero-copy submits run the aligned tiled kernel with a CAPPED grid (workgroups loop over the tiles) on up to
+    "zero_copy_streams" streams: every cap (1 workgroup, fewer than / more than the tiles, the default) and stream count
+    gives the oracle's bytes; several submits in flight on rotating buffers; strided bands take the same path."""
+    h, w, c, n = 96, 320, 3, 9
+    host = O.lcg_stream(4 * n, h, w, c)
+    want = O.blur_batch(host, radius)
+    nbytes = n * h * w * c
+    bufs = [(L.mi_blur_host_alloc(nbytes), L.mi_blur_host_alloc(nbytes)) for _ in range(4)]
+    try:
+        for k, (pi, _po) in enumerate(bufs):
+            C.memmove(pi, host[k * n:(k + 1) * n].ctypes.data, nbytes)
+        for streams, cap in ((1, 1), (4, 1), (2, 5), (4, 24), (3, 100000), (4, 0)):
+            pkg.check(L.mi_blur_set_option(b"zero_copy_streams", streams))
+            pkg.check(L.mi_blur_set_option(b"zero_copy_blocks", cap))
+            with pkg.Context(0, w, h, c, radius, max_batch=n, n_slots=4) as ctx:
+                for rnd in range(3):
+                    for (pi, po) in bufs:
+                        if rnd == 0:
+                            C.memset(po, 0xEE, nbytes)
+                        ctx.submit(pi, po, n)
+                ctx.sync()
+                assert L.mi_blur_zero_copy_launches(ctx.h) == 12
+                for k, (_pi, po) in enumerate(bufs):
+                    got = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(po)).reshape(n, h, w, c)
+                    assert np.array_equal(got, want[k * n:(k + 1) * n]), (streams, cap, k)
+    finally:
+        pkg.check(L.mi_blur_set_option(b"zero_copy_streams", 4))
+        pkg.check(L.mi_blur_set_option(b"zero_copy_blocks", 24))
+        for (pi, po) in bufs:
+            L.mi_blur_host_free(pi); L.mi_blur_host_free(po)
+
+
 def test_submit_bands_strided_batch(pkg, L, O, torch_cuda):
     """Approach 2 for a whole batch (mi_blur_submit_bands): the same rows of every image of a contiguous batch
     stream, gathered by one 2-D DMA (pinned memory) or through the pinned staging slot (pageable memory)."""
