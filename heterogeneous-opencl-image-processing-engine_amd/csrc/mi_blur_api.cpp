@@ -187,6 +187,12 @@ struct mi_blur_ctx {
     size_t ev_used = 0;
     uint64_t timed_launches = 0, timed_bytes_alg = 0;   // resident launches that carried timestamp events
     uint64_t zero_copy_launches = 0;
+    // Zero-copy launches of one context may overlap (several streams).  Their kernel bucket is the time during which at
+    // least ONE of them was executing — the union of the dispatch intervals, measured against a reference event recorded
+    // before the first of them since the last sync — not the sum of overlapping durations.
+    hipEvent_t zc_ref = nullptr;
+    bool zc_ref_valid = false;
+    double zc_covered_ms = 0.0;                                  // the union so far reaches this far past zc_ref
     // fused stream: per-batch completion counters (device) and flags (pinned host memory)
     unsigned *fused_count = nullptr, *fused_host = nullptr;    // device counters; pinned host copy for polling
     int fused_cap = 0, fused_batches = 0;
@@ -296,9 +302,16 @@ static int finish_slot(mi_blur_ctx *c, Slot &s)
 {
     if (!s.busy) return MI_BLUR_OK;
     float ms = 0.f;
-    if (s.zero_copy) {                                           // launched on the context's zero-copy stream, not the slot's
+    if (s.zero_copy) {                                           // launched on one of the context's zero-copy streams
         HIP_TRY(hipEventSynchronize(s.ke));
-        if (hipEventElapsedTime(&ms, s.ks, s.ke) == hipSuccess) c->tm.kernel_ms += ms;
+        float a = 0.f, b = 0.f;
+        if (c->zc_ref_valid && hipEventElapsedTime(&a, c->zc_ref, s.ks) == hipSuccess && hipEventElapsedTime(&b, c->zc_ref, s.ke) == hipSuccess && b >= a) {
+            const double from = std::max((double)a, c->zc_covered_ms);
+            if ((double)b > from) c->tm.kernel_ms += (double)b - from;
+            c->zc_covered_ms = std::max(c->zc_covered_ms, (double)b);
+        } else if (hipEventElapsedTime(&ms, s.ks, s.ke) == hipSuccess) {
+            c->tm.kernel_ms += ms;
+        }
         (void)hipGetLastError();
         s.zero_copy = false;
         s.busy = false;
@@ -345,6 +358,7 @@ extern "C" int mi_blur_sync(mi_blur_ctx *c, mi_blur_timing *timing)
         }
         for (auto &s : c->slots) HIP_TRY(hipStreamSynchronize(s.stream));
         harvest_resident(c);
+        c->zc_ref_valid = false;                                 // everything drained: the next zero-copy launch starts a new window
     }
     if (timing) *timing = c->tm;
     return MI_BLUR_OK;
@@ -384,6 +398,7 @@ extern "C" void mi_blur_destroy(mi_blur_ctx *c)
         for (auto &s : c->slots) { if (s.stream) (void)hipStreamSynchronize(s.stream); }
         for (auto &s : c->slots) free_slot(s);
         for (auto &t : c->ev_pool) { (void)hipEventDestroy(t.s); (void)hipEventDestroy(t.e); }
+        if (c->zc_ref) (void)hipEventDestroy(c->zc_ref);
         if (c->fused_count) (void)hipFree(c->fused_count);
         if (c->fused_host) (void)hipHostFree(c->fused_host);
         if (c->fused_poll) (void)hipStreamDestroy(c->fused_poll);
@@ -446,6 +461,13 @@ static int submit_common(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_o
                 d.in_stride = (long long)in_stride; d.out_stride = (long long)out_stride;
                 d.stream = zs; d.start = s.ks; d.stop = s.ke;
                 d.max_blocks = tunables().zero_copy_blocks;
+                // once per sync window, in front of its first launch (and again every ~10 s of a window that never syncs,
+                // so the float milliseconds since the reference keep their resolution)
+                if (!c->zc_ref_valid || c->zc_covered_ms > 10e3) {
+                    if (!c->zc_ref) HIP_TRY(hipEventCreate(&c->zc_ref));
+                    HIP_TRY(hipEventRecord(c->zc_ref, zs));
+                    c->zc_ref_valid = true; c->zc_covered_ms = 0.0;
+                }
                 rc = launch(d);
                 if (rc) return rc;
                 s.zero_copy = true;                            // only now: a failed launch leaves the slot idle and staged

@@ -130,7 +130,8 @@ typedef struct mi_blur_ctx mi_blur_ctx;
 
 typedef struct mi_blur_timing {      /* cumulative since create / last reset; mirrors :411-412 */
     double h2d_ms;                   /* transfer IN  (time_*_transfer_in)  */
-    double kernel_ms;                /* kernel       (time_*_kernel)       */
+    double kernel_ms;                /* kernel       (time_*_kernel); zero-copy submits that overlap count the time at
+                                        least one of them was executing, not the sum of their durations */
     double d2h_ms;                   /* transfer OUT (time_*_transfer_out) */
     uint64_t bytes_h2d, bytes_d2h;
     uint64_t bytes_alg;              /* algorithmic bytes = 2*W*rows*C per image processed */

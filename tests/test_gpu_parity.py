@@ -367,13 +367,18 @@ def test_zero_copy_capped_grid_and_streams(pkg, L, O, torch_cuda, radius):
             pkg.check(L.mi_blur_set_option(b"zero_copy_streams", streams))
             pkg.check(L.mi_blur_set_option(b"zero_copy_blocks", cap))
             with pkg.Context(0, w, h, c, radius, max_batch=n, n_slots=4) as ctx:
+                for (_pi, po) in bufs:
+                    C.memset(po, 0xEE, nbytes)
+                t0 = time.perf_counter()
                 for rnd in range(3):
                     for (pi, po) in bufs:
-                        if rnd == 0:
-                            C.memset(po, 0xEE, nbytes)
                         ctx.submit(pi, po, n)
-                ctx.sync()
+                tm = ctx.sync()
+                wall_ms = (time.perf_counter() - t0) * 1e3
                 assert L.mi_blur_zero_copy_launches(ctx.h) == 12
+                # overlapping launches: the kernel bucket is the time at least one of them was executing, so it cannot
+                # exceed the wall clock of the loop (a sum of overlapping durations would, with 4 streams)
+                assert 0 < tm["kernel_ms"] <= wall_ms * 1.02 + 0.05, (streams, cap, tm["kernel_ms"], wall_ms)
                 for k, (_pi, po) in enumerate(bufs):
                     got = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(po)).reshape(n, h, w, c)
                     assert np.array_equal(got, want[k * n:(k + 1) * n]), (streams, cap, k)
