@@ -247,6 +247,7 @@ struct TiledParams {
     unsigned nblocks;
     int xcd;                          // blockIdx -> tile map: 0 identity, 1 XCD-contiguous, r >= 2 runs of r tiles dealt to the XCDs in turn
     int debug_copy;                   // ablation only: skip the arithmetic, store the staged centre chunk
+    unsigned long long *xcd_times;    // diagnostics only (nullptr normally): per workgroup {end << 4 | XCC_ID, start}
     int tail;                         // RAG: bytes of the row's last chunk that exist (1..16); 16 otherwise
 };
 
@@ -447,10 +448,26 @@ __device__ __forceinline__ void tiled_tile(const TiledParams &p, unsigned L)
     }
 }
 
+// Diagnostics: which XCD does a launch wait for?  Every workgroup stores (end time << 4 | XCC_ID) and its start time
+// (s_memrealtime, 100 MHz) in slots of its own — plain stores, no atomics, so the launch being examined is not slowed.
+// Off (nullptr) unless mi_blur_set_option("debug_xcd_times", 1); the host folds the slots per XCD.
+constexpr unsigned XCD_DEBUG_SLOTS = 1u << 20;
+__device__ __forceinline__ void xcd_time_mark(unsigned long long *t, unsigned long long t0)
+{
+    if (threadIdx.x == 0 && blockIdx.x < XCD_DEBUG_SLOTS) {
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        t[2u * blockIdx.x] = ((unsigned long long)__builtin_amdgcn_s_memrealtime() << 4) | (id & 7u);
+        t[2u * blockIdx.x + 1] = t0;
+    }
+}
+
 template <int C, int R, int RPG, bool DMA, bool SHFL = false, bool RAG = false>
 __global__ __launch_bounds__(256) void blur_tiled_kernel(const TiledParams p)
 {
+    const unsigned long long t0 = p.xcd_times ? __builtin_amdgcn_s_memrealtime() : 0ull;
     tiled_tile<C, R, RPG, DMA, SHFL, RAG>(p, xcd_map(blockIdx.x, p.nblocks, p.xcd));
+    if (p.xcd_times) xcd_time_mark(p.xcd_times, t0);
 }
 
 // Capped-grid form: at most `gridDim.x` workgroups walk the launch's tiles (block b takes tiles b, b + G, b + 2G ...).
@@ -714,7 +731,7 @@ static std::mutex &tunables_mutex() { static std::mutex m; return m; }
 static Tunables &tunables_storage()
 {
     static Tunables t = [] {
-        Tunables v{1, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0, 4, 24, 1};  // rpg 0 / stream_bh 0 = choose per launch
+        Tunables v{1, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0, 4, 24, 1, 0};  // rpg 0 / stream_bh 0 = choose per launch
         if (const char *e = getenv("MI_BLUR_STAGE")) v.stage_dma = strcmp(e, "reg") != 0;
         if (const char *e = getenv("MI_BLUR_RPG")) { const int r = atoi(e); v.rpg = (r == 4 || r == 8 || r == 16) ? r : 0; }
         if (const char *e = getenv("MI_BLUR_XCD")) v.xcd_remap = atoi(e) != 0;
@@ -732,6 +749,20 @@ void set_tunables(const Tunables &t)
     std::lock_guard<std::mutex> g(tunables_mutex());
     tunables_storage() = t;
 }
+
+// Diagnostics buffer (2 x u64 per workgroup, XCD_DEBUG_SLOTS workgroups, on the current device), allocated on first use
+// and never freed.
+unsigned long long *debug_xcd_buffer()
+{
+    static unsigned long long *buf = nullptr;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (hipMalloc((void **)&buf, (size_t)XCD_DEBUG_SLOTS * 16) != hipSuccess) { (void)hipGetLastError(); buf = nullptr; }
+        else (void)hipMemset(buf, 0, (size_t)XCD_DEBUG_SLOTS * 16);
+    });
+    return buf;
+}
+unsigned debug_xcd_slots() { return XCD_DEBUG_SLOTS; }
 
 // The ragged form of the tiled kernel: any pitch of at least one chunk, any pointer alignment.
 static bool ragged_eligible(int width, int channels)
@@ -879,6 +910,7 @@ static int launch_tiled(const LaunchDesc &d, const Tunables &tun, bool ragged = 
     }
     p.xcd = xmap;
     p.debug_copy = tun.debug_copy;
+    p.xcd_times = tun.debug_xcd_times ? debug_xcd_buffer() : nullptr;
     p.tail = pitch % 16 ? pitch % 16 : 16;
 
     const dim3 grid((unsigned)nblocks), block((unsigned)((p.ncols * p.ngroups + 63) / 64 * 64));

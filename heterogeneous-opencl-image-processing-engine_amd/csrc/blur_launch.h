@@ -58,8 +58,11 @@ struct Tunables {
     int zero_copy_streams;   // streams the zero-copy submits of a context alternate over (1 = one in-order stream)
     int zero_copy_blocks;    // zero-copy submits: cap on resident workgroups (0 = no cap: one workgroup per tile)
     int stream_updown;   // streaming variant: 1 (default) = odd bands march upwards, so both readers of a band seam come at the same time
+    int debug_xcd_times; // diagnostics: the tiled kernel's workgroups leave start/end times per XCD (mi_blur_debug_xcd_times)
 };
 Tunables tunables();
+unsigned long long *debug_xcd_buffer();
+unsigned debug_xcd_slots();
 void set_tunables(const Tunables &t);
 
 }  // namespace mi_blur

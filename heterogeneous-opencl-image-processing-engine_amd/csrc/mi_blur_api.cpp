@@ -92,6 +92,7 @@ extern "C" int mi_blur_set_option(const char *key, int value)
     else if (!strcmp(key, "stream_updown")) t.stream_updown = value != 0;
     else if (!strcmp(key, "zero_copy_streams")) { if (value < 1 || value > 8) return MI_BLUR_ERR_INVALID; t.zero_copy_streams = value; }
     else if (!strcmp(key, "zero_copy_blocks")) { if (value < 0 || value > (1 << 20)) return MI_BLUR_ERR_INVALID; t.zero_copy_blocks = value; }
+    else if (!strcmp(key, "debug_xcd_times")) t.debug_xcd_times = value != 0;
     else if (!strcmp(key, "xcd_run")) { if (value < 0 || value > (1 << 20)) return MI_BLUR_ERR_INVALID; t.xcd_run = value; }
     else return MI_BLUR_ERR_INVALID;
     set_tunables(t);
@@ -796,6 +797,29 @@ extern "C" void mi_blur_fill_synthetic(uint8_t *host, int width, int height, int
 {
     if (host && width > 0 && height > 0 && channels > 0)
         fill_synthetic(host, width, height, channels, first_index, n_images, n_threads);
+}
+
+// Diagnostics (see mi_blur.h): fold the per-workgroup times of the tiled kernel per XCD, and optionally re-arm the slots.
+extern "C" int mi_blur_debug_xcd_times(uint64_t end_ticks[8], uint64_t begin_ticks[8], int rearm)
+{
+    unsigned long long *d = debug_xcd_buffer();
+    if (!d) return MI_BLUR_ERR_NOMEM;
+    const size_t n = debug_xcd_slots();
+    std::vector<unsigned long long> h;
+    try { h.resize(2 * n); } catch (...) { return MI_BLUR_ERR_NOMEM; }
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h.data(), d, 16 * n, hipMemcpyDeviceToHost));
+    uint64_t e[8] = {0, 0, 0, 0, 0, 0, 0, 0}, b[8];
+    for (int i = 0; i < 8; i++) b[i] = ~0ull;
+    for (size_t i = 0; i < n; i++) {
+        if (!h[2 * i]) continue;                                  // workgroup slot not written since the last re-arm
+        const int x = (int)(h[2 * i] & 7u);
+        e[x] = std::max<uint64_t>(e[x], h[2 * i] >> 4);
+        b[x] = std::min<uint64_t>(b[x], h[2 * i + 1]);
+    }
+    for (int i = 0; i < 8; i++) { if (end_ticks) end_ticks[i] = e[i]; if (begin_ticks) begin_ticks[i] = b[i]; }
+    if (rearm) HIP_TRY(hipMemset(d, 0, 16 * n));
+    return MI_BLUR_OK;
 }
 
 extern "C" uint64_t mi_blur_fnv1a64(const uint8_t *host, size_t n) { return fnv1a64(host, n); }

@@ -265,6 +265,12 @@ int mi_blur_resident_peek(mi_blur_ctx *ctx, int pool_index, uint8_t *host_out, i
 int mi_blur_cpu_run(const uint8_t *in, uint8_t *out, int width, int height, int channels,
                     int radius, int n_images, int n_threads);
 
+/* Developer diagnostics.  With mi_blur_set_option("debug_xcd_times", 1) every workgroup of the tiled kernel leaves its
+ * start and end time (100 MHz ticks) in a slot of the XCD it ran on; this call waits for the device, returns per XCD the
+ * LATEST end and the EARLIEST start seen since the last re-arm, and re-arms the slots when asked (call it once with
+ * rearm = 1 before the launches to be examined).  Shows which XCD a launch waits for (profiles/r02_xcd_finish_times.txt). */
+int mi_blur_debug_xcd_times(uint64_t end_ticks[8], uint64_t begin_ticks[8], int rearm);
+
 /* Synthetic stream generator shared by hosts, bench and tests. */
 void mi_blur_fill_synthetic(uint8_t *host, int width, int height, int channels,
                             int first_index, int n_images, int n_threads);

@@ -928,3 +928,25 @@ def test_headline_stream_golden_hash(pkg, L, O, torch_cuda, golden):
                 assert f"{int(per[int(k)]):016x}" == v, (form, k)
             assert per_digest == e["per_image_fnv_digest"], form
             assert whole == e["out_fnv"], form
+
+
+def test_debug_xcd_times_diagnostics(pkg, L, O, torch_cuda):
+    """Developer diagnostics: with "debug_xcd_times" on, the tiled kernel's workgroups leave per-XCD start/end times; the
+    output bytes are unchanged, every XCD that ran a workgroup reports end > start, and re-arming clears the slots."""
+    host = O.lcg_stream(40, 256, 256, 3)
+    want = O.blur_batch(host, 1)
+    end, beg = (C.c_uint64 * 8)(), (C.c_uint64 * 8)()
+    try:
+        pkg.check(L.mi_blur_set_option(b"debug_xcd_times", 1))
+        pkg.check(L.mi_blur_debug_xcd_times(end, beg, 1))
+        got = gpu_blur(pkg, L, torch_cuda, host, 1, pkg.VARIANT_TILED)
+        assert np.array_equal(got, want)
+        pkg.check(L.mi_blur_debug_xcd_times(end, beg, 1))
+        ran = [i for i in range(8) if end[i]]
+        assert len(ran) == 8, "320 workgroups are dealt over all 8 XCDs"
+        assert all(end[i] > beg[i] for i in ran)
+        assert (max(end) - min(beg)) / 100.0 < 5000.0               # 100 MHz ticks: the launch took well under 5 ms
+        pkg.check(L.mi_blur_debug_xcd_times(end, beg, 0))
+        assert not any(end)                                          # re-armed: nothing since
+    finally:
+        pkg.check(L.mi_blur_set_option(b"debug_xcd_times", 0))
