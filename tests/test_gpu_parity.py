@@ -950,3 +950,26 @@ def test_debug_xcd_times_diagnostics(pkg, L, O, torch_cuda):
         assert not any(end)                                          # re-armed: nothing since
     finally:
         pkg.check(L.mi_blur_set_option(b"debug_xcd_times", 0))
+
+
+def test_random_shapes_auto_dispatch(pkg, L, O, torch_cuda):
+    """Seeded sweep through the dispatcher (aligned tiled / ragged tiled / generic, chosen by shape): any width, height,
+    1-5 channels, both radii, batches, output row ranges inside a band (Approach-2 form: clamp at the band's own edges,
+    only rows [y0, y1) produced) — every case byte-equal to the oracle."""
+    rng = np.random.default_rng(2025)
+    try:
+        for case in range(60):
+            c = int(rng.choice([1, 2, 3, 3, 3, 4, 5]))
+            w = int(rng.choice([rng.integers(1, 24), rng.integers(16, 400), 16 * int(rng.integers(1, 40)) // int(np.gcd(16, c)) or 16]))
+            h = int(rng.integers(1, 70))
+            r = int(rng.choice([1, 2]))
+            n = int(rng.integers(1, 5))
+            y0 = int(rng.integers(0, h))
+            y1 = int(rng.integers(y0 + 1, h + 1))
+            host = rng.integers(0, 256, (n, h, w, c), dtype=np.uint8)
+            want = want_batch(O, host, r)[:, y0:y1]
+            for opts in ({}, {"rows_per_thread": int(rng.choice([4, 8, 16])), "stage_dma": int(rng.integers(0, 2)), "xcd_run": int(rng.choice([0, 3]))}):
+                got = gpu_blur(pkg, L, torch_cuda, host, r, pkg.VARIANT_AUTO, y0=y0, y1=y1, opts=opts)
+                assert np.array_equal(got, want), (case, h, w, c, r, n, y0, y1, opts)
+    finally:
+        reset_opts(L)
