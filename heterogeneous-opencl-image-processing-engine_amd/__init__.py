@@ -28,7 +28,7 @@ os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "0")
 ARCH = "gfx950"
 
 DEVICE_CPU = -1
-VARIANT_AUTO, VARIANT_GENERIC, VARIANT_TILED, VARIANT_STREAM = 0, 1, 2, 3
+VARIANT_AUTO, VARIANT_GENERIC, VARIANT_TILED, VARIANT_STREAM, VARIANT_DIRECT = 0, 1, 2, 3, 4
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_NOMEM, ERR_STATE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 UNIQUE_ID_BYTES = 128
 

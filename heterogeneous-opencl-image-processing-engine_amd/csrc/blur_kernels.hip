@@ -685,6 +685,88 @@ __global__ __launch_bounds__(256) void blur_stream_kernel(const StreamParams p)
 }
 
 // ----------------------------------------------------------------------------------
+// direct kernel (trial): no LDS at all — rows go from global memory straight into registers
+// ----------------------------------------------------------------------------------
+// What keeps an elementwise kernel at 6.2 TB/s on this part is the amount of data it has in flight: registers, not the
+// 160 KB of LDS, hold it.  Here every lane loads the BH + 2R rows of its own 16-byte chunk column with plain 16-byte
+// loads, all issued up front (hipcc counts them: a row is consumed as soon as IT has landed), takes the 8 bytes either side
+// from the neighbouring lanes' registers (v_mov_b32_dpp wave_shr:1 / wave_shl:1) and keeps the 2R+1-row window of
+// horizontal sums in registers.  Lanes are consecutive chunks of the flattened (image, band, chunk column) space, 62 per
+// wave: lanes 0 and 63 duplicate the neighbouring waves' edge chunks and only supply halo bytes.  No barrier, no LDS, no
+// workgroup-level phase: ~10 KB in flight per wave, 16-20 waves per CU.
+struct DirectParams {
+    const uint8_t *in;
+    uint8_t *out;
+    long long in_stride, out_stride;
+    long long total;                  // n_images * nbands * cpr chunk columns of work
+    int pitch, cpr;
+    int H, y0, y1;
+    int nbands;
+    unsigned nblocks;
+    int xcd;
+};
+
+template <int C, int R, int BH>
+__global__ __launch_bounds__(256) void blur_direct_kernel(const DirectParams p)
+{
+    constexpr int WIN = 2 * R + 1, NR = BH + 2 * R;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned B = xcd_map(blockIdx.x, p.nblocks, p.xcd);
+    const long long fl = (long long)(B * 4u + (unsigned)wave) * 62 - 1 + lane;
+    const bool inrange = fl >= 0 && fl < p.total;
+    const unsigned f = (unsigned)(fl < 0 ? 0 : (fl >= p.total ? p.total - 1 : fl));
+    const unsigned col = f % (unsigned)p.cpr, t2 = f / (unsigned)p.cpr;
+    const unsigned band = t2 % (unsigned)p.nbands;
+    const long long img = (long long)(t2 / (unsigned)p.nbands);
+    const bool compute = inrange && lane >= 1 && lane <= 62;
+    const int row0 = p.y0 + (int)band * BH;
+    const int rows_out = compute ? min(BH, p.y1 - row0) : 0;
+    const bool at_start = col == 0, at_end = (int)col == p.cpr - 1;
+    const bool any_edge = __builtin_amdgcn_ballot_w64(at_start || at_end) != 0ull;
+    const uint8_t *src = p.in + img * p.in_stride + (size_t)col * 16u;
+    uint8_t *dst = p.out + img * p.out_stride + (size_t)(row0 - p.y0) * (size_t)p.pitch + (size_t)col * 16u;
+
+    uint4 rows[NR];
+#pragma unroll
+    for (int j = 0; j < NR; j++)
+        rows[j] = *reinterpret_cast<const uint4 *>(src + (size_t)min(max(row0 - R + j, 0), p.H - 1) * (size_t)p.pitch);
+
+    uint32_t hw[WIN][8];
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        uint32_t w[8];
+        const uint4 c = rows[j];
+        w[2] = c.x; w[3] = c.y; w[4] = c.z; w[5] = c.w;
+        w[0] = __builtin_amdgcn_update_dpp(0u, c.z, 0x138, 0xf, 0xf, false);    // wave_shr:1: lane i takes lane i-1's last two dwords
+        w[1] = __builtin_amdgcn_update_dpp(0u, c.w, 0x138, 0xf, 0xf, false);
+        w[6] = __builtin_amdgcn_update_dpp(0u, c.x, 0x130, 0xf, 0xf, false);    // wave_shl:1: lane i+1's first two
+        w[7] = __builtin_amdgcn_update_dpp(0u, c.y, 0x130, 0xf, 0xf, false);
+        hrow_window<C, R, rowpass_default<R>>(w, any_edge, at_start, at_end, hw[j % WIN]);
+        if (j >= 2 * R) {
+            const int i = j - 2 * R;                                            // output row completed by this input row
+            uint32_t o[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if constexpr (R == 1) {
+                    const uint32_t se = (((hw[(j + 2) % WIN][q] << 1) + hw[(j + 1) % WIN][q]) + hw[j % WIN][q]) << 4;
+                    const uint32_t so = (((hw[(j + 2) % WIN][4 + q] << 1) + hw[(j + 1) % WIN][4 + q]) + hw[j % WIN][4 + q]) << 4;
+                    o[q] = __builtin_amdgcn_perm(so, se, 0x07030501u);
+                } else {
+                    // rows i..i+4 sit in window slots (j+1), (j+2), (j+3), (j+4), j (mod 5)
+                    const uint32_t se = mad6(hw[(j + 3) % WIN][q], ((hw[(j + 2) % WIN][q] + hw[(j + 4) % WIN][q]) << 2) + (hw[(j + 1) % WIN][q] + hw[j % WIN][q]));
+                    const uint32_t so = mad6(hw[(j + 3) % WIN][4 + q], ((hw[(j + 2) % WIN][4 + q] + hw[(j + 4) % WIN][4 + q]) << 2) + (hw[(j + 1) % WIN][4 + q] + hw[j % WIN][4 + q]));
+                    o[q] = __builtin_amdgcn_perm(so, se, 0x07030501u);
+                }
+            }
+            if (i < rows_out) {
+                u32x4 v; v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
+                *reinterpret_cast<u32x4 *>(dst + (size_t)i * (size_t)p.pitch) = v;
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------
 // generic kernel: one output byte per thread
 // ----------------------------------------------------------------------------------
 struct GenericParams {
@@ -731,10 +813,11 @@ static std::mutex &tunables_mutex() { static std::mutex m; return m; }
 static Tunables &tunables_storage()
 {
     static Tunables t = [] {
-        Tunables v{1, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0, 4, 24, 1, 0};  // rpg 0 / stream_bh 0 = choose per launch
+        Tunables v{1, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0, 4, 24, 1, 1, 8, 0};  // rpg 0 / stream_bh 0 = choose per launch
         if (const char *e = getenv("MI_BLUR_STAGE")) v.stage_dma = strcmp(e, "reg") != 0;
         if (const char *e = getenv("MI_BLUR_RPG")) { const int r = atoi(e); v.rpg = (r == 4 || r == 8 || r == 16) ? r : 0; }
         if (const char *e = getenv("MI_BLUR_XCD")) v.xcd_remap = atoi(e) != 0;
+        if (const char *e = getenv("MI_BLUR_DIRECT")) { const int r = atoi(e); if (r >= 0 && r <= 2) v.prefer_direct = r; }
         return v;
     }();
     return t;
@@ -996,6 +1079,58 @@ static int launch_stream(const LaunchDesc &d, const Tunables &tun)
     return MI_BLUR_ERR_INVALID;
 }
 
+template <int BH>
+static int launch_direct_bh(const LaunchDesc &d, const Tunables &tun);
+
+// The direct kernel numbers its work in 32 bits: images x bands x chunk columns.
+static bool direct_fits(const LaunchDesc &d)
+{
+    const long long cpr = (long long)d.width * d.channels / 16, rows = d.y1 - d.y0;
+    return (long long)d.n_images * ((rows + 3) / 4) * cpr < 0x7fffffffLL;
+}
+
+static int launch_direct(const LaunchDesc &d, const Tunables &tun)
+{
+    if (d.channels == 3 && tun.direct_bh == 4) return launch_direct_bh<4>(d, tun);
+    if (d.channels == 3 && tun.direct_bh == 16) return launch_direct_bh<16>(d, tun);
+    if (d.channels == 3 && tun.direct_bh == 12) return launch_direct_bh<12>(d, tun);
+    return launch_direct_bh<8>(d, tun);
+}
+
+template <int BH>
+static int launch_direct_bh(const LaunchDesc &d, const Tunables &tun)
+{
+    const int pitch = d.width * d.channels, cpr = pitch / 16, rows = d.y1 - d.y0;
+    DirectParams p{};
+    p.in = d.in; p.out = d.out;
+    p.in_stride = (long long)d.band_rows * pitch;
+    p.out_stride = (long long)rows * pitch;
+    p.pitch = pitch; p.cpr = cpr; p.H = d.band_rows; p.y0 = d.y0; p.y1 = d.y1;
+    p.nbands = (rows + BH - 1) / BH;
+    p.total = (long long)d.n_images * p.nbands * cpr;
+    if (p.total >= 0x7fffffffLL) return MI_BLUR_ERR_INVALID;
+    const long long waves = (p.total + 61) / 62, nblocks = (waves + 3) / 4;
+    p.nblocks = (unsigned)nblocks;
+    p.xcd = (tun.xcd_remap && nblocks >= 16) ? 1 : 0;
+    const dim3 grid((unsigned)nblocks), block(256);
+    if constexpr (BH != 8) {
+        return d.radius == 1 ? do_launch(blur_direct_kernel<3, 1, BH>, grid, block, 0, d, p)
+                             : do_launch(blur_direct_kernel<3, 2, BH>, grid, block, 0, d, p);
+    } else {
+        switch (d.channels * 10 + d.radius) {
+        case 11: return do_launch(blur_direct_kernel<1, 1, BH>, grid, block, 0, d, p);
+        case 12: return do_launch(blur_direct_kernel<1, 2, BH>, grid, block, 0, d, p);
+        case 21: return do_launch(blur_direct_kernel<2, 1, BH>, grid, block, 0, d, p);
+        case 22: return do_launch(blur_direct_kernel<2, 2, BH>, grid, block, 0, d, p);
+        case 31: return do_launch(blur_direct_kernel<3, 1, BH>, grid, block, 0, d, p);
+        case 32: return do_launch(blur_direct_kernel<3, 2, BH>, grid, block, 0, d, p);
+        case 41: return do_launch(blur_direct_kernel<4, 1, BH>, grid, block, 0, d, p);
+        case 42: return do_launch(blur_direct_kernel<4, 2, BH>, grid, block, 0, d, p);
+        }
+        return MI_BLUR_ERR_INVALID;
+    }
+}
+
 static int launch_generic(const LaunchDesc &d)
 {
     GenericParams p{};
@@ -1036,10 +1171,22 @@ int launch(const LaunchDesc &d)
     switch (d.variant) {
     case MI_BLUR_VARIANT_AUTO:
         if (!can_tile) return can_rag ? launch_tiled(d, tun, true) : launch_generic(d);
-        return tun.prefer_stream ? launch_stream(d, tun) : launch_tiled(d, tun);
+        if (tun.prefer_stream) return launch_stream(d, tun);
+        // Direct (LDS-free) or tiled?  Measured on MI355X (profiles/r02_direct_kernel.txt): the direct kernel wins every
+        // 5x5 launch (5-22 %) and the 3x3 launches that do not fill the chip for long (a batch of 35 256x256 images: 5.4
+        // against 6.8 us; parity near 150-400 MB of output); big 3x3 launches stay with the LDS tiles (1-4 % better there:
+        // 1.06x instead of 1.25x row traffic into the CUs), and so do small 3x3 launches that the caller overlaps on several
+        // streams (10.7 against 9.3 M img/s for the batch-35 stream on 4 streams; alone on one stream 4.5 against 5.4).
+        // Zero-copy submits keep the capped-grid tiled kernel.
+        if (direct_fits(d) && d.max_blocks <= 0 &&
+            (tun.prefer_direct == 2 ||
+             (tun.prefer_direct == 1 && (d.radius == 2 || (dense_out * d.n_images <= (128LL << 20) && d.concurrent <= 1)))))
+            return launch_direct(d, tun);
+        return launch_tiled(d, tun);
     case MI_BLUR_VARIANT_GENERIC: return launch_generic(d);
     case MI_BLUR_VARIANT_TILED: return can_tile ? launch_tiled(d, tun) : can_rag ? launch_tiled(d, tun, true) : MI_BLUR_ERR_INVALID;
     case MI_BLUR_VARIANT_STREAM: return can_tile ? launch_stream(d, tun) : MI_BLUR_ERR_INVALID;
+    case MI_BLUR_VARIANT_DIRECT: return (can_tile && direct_fits(d)) ? launch_direct(d, tun) : MI_BLUR_ERR_INVALID;
     }
     return MI_BLUR_ERR_INVALID;
 }

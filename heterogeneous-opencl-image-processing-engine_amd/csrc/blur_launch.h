@@ -14,6 +14,8 @@ struct LaunchDesc {
     int y0, y1;             // output rows [y0,y1) of each band
     long long in_stride, out_stride;  // bytes between consecutive bands / output blocks; 0 = laid end to end.
                             // Non-dense strides are taken by the tiled kernel only (multiples of 16).
+    int concurrent;         // hint: how many streams the caller rotates launches like this one over (0/1 = one after another).
+                            // Small 3x3 launches that overlap with their like run faster as LDS tiles, alone as the direct kernel.
     int max_blocks;         // > 0: cap the grid of the aligned tiled kernel; its workgroups then loop over the tiles (zero-copy submits)
     int variant;            // mi_blur_variant
     hipStream_t stream;
@@ -58,6 +60,9 @@ struct Tunables {
     int zero_copy_streams;   // streams the zero-copy submits of a context alternate over (1 = one in-order stream)
     int zero_copy_blocks;    // zero-copy submits: cap on resident workgroups (0 = no cap: one workgroup per tile)
     int stream_updown;   // streaming variant: 1 (default) = odd bands march upwards, so both readers of a band seam come at the same time
+    int prefer_direct;   // AUTO and the direct (register-staged, LDS-free) variant: 0 never, 1 (default) where it measured faster
+                         // (every 5x5 launch, 3x3 launches up to 128 MiB of output), 2 whenever the shape is eligible
+    int direct_bh;       // direct variant: output rows per lane (8; 4 | 12 | 16 instantiated for C = 3 only, A/B runs)
     int debug_xcd_times; // diagnostics: the tiled kernel's workgroups leave start/end times per XCD (mi_blur_debug_xcd_times)
 };
 Tunables tunables();

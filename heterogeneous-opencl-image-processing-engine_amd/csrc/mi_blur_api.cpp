@@ -92,6 +92,8 @@ extern "C" int mi_blur_set_option(const char *key, int value)
     else if (!strcmp(key, "stream_updown")) t.stream_updown = value != 0;
     else if (!strcmp(key, "zero_copy_streams")) { if (value < 1 || value > 8) return MI_BLUR_ERR_INVALID; t.zero_copy_streams = value; }
     else if (!strcmp(key, "zero_copy_blocks")) { if (value < 0 || value > (1 << 20)) return MI_BLUR_ERR_INVALID; t.zero_copy_blocks = value; }
+    else if (!strcmp(key, "prefer_direct")) { if (value < 0 || value > 2) return MI_BLUR_ERR_INVALID; t.prefer_direct = value; }
+    else if (!strcmp(key, "direct_bh")) { if (value != 4 && value != 8 && value != 12 && value != 16) return MI_BLUR_ERR_INVALID; t.direct_bh = value; }
     else if (!strcmp(key, "debug_xcd_times")) t.debug_xcd_times = value != 0;
     else if (!strcmp(key, "xcd_run")) { if (value < 0 || value > (1 << 20)) return MI_BLUR_ERR_INVALID; t.xcd_run = value; }
     else return MI_BLUR_ERR_INVALID;
@@ -501,6 +503,7 @@ static int submit_common(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_o
         d.in = s.d_in; d.out = s.d_out; d.width = c->W; d.band_rows = band_rows; d.channels = c->C;
         d.radius = c->R; d.n_images = n_images; d.y0 = y0; d.y1 = y1; d.variant = MI_BLUR_VARIANT_AUTO;
         d.stream = s.stream; d.start = s.ks; d.stop = s.ke;
+        d.concurrent = (int)c->slots.size();
         rc = launch(d);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(s.ev[2], s.stream));
@@ -648,6 +651,7 @@ extern "C" int mi_blur_resident_run(mi_blur_ctx *c, int n_images, int batch, int
         d.out = c->pool_out + (size_t)c->cursor * c->image_bytes;
         d.width = c->W; d.band_rows = c->H; d.channels = c->C; d.radius = c->R; d.n_images = b;
         d.y0 = 0; d.y1 = c->H; d.variant = MI_BLUR_VARIANT_AUTO; d.stream = s.stream;
+        d.concurrent = (int)c->slots.size();
         if (timed) {
             if (c->ev_used == c->ev_pool.size()) {
                 TimedLaunch t{};

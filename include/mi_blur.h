@@ -51,11 +51,13 @@ typedef enum mi_blur_status {
 
 /* Kernel variant selector for mi_blur_enqueue_ex (tests force each path). */
 typedef enum mi_blur_variant {
-    MI_BLUR_VARIANT_AUTO = 0,        /* LDS-tiled vector kernel when pitch%16==0 && channels<=4, else generic */
+    MI_BLUR_VARIANT_AUTO = 0,        /* pitch%16==0 && channels<=4 && aligned pointers: the direct kernel (5x5; small 3x3 launches) or
+                                        the LDS-tiled one (big 3x3 launches); other rows of >= 16 B: ragged tiled; else generic */
     MI_BLUR_VARIANT_GENERIC = 1,     /* one output byte per thread, any shape */
     MI_BLUR_VARIANT_TILED = 2,       /* LDS halo tile + 16-B vector loads (ragged form for odd pitches; _INVALID if C > 4 or rows < 16 B) */
     MI_BLUR_VARIANT_STREAM = 3       /* barrier-free: every wave streams its band through a wave-private LDS row ring
-                                        (LDS-DMA, counted vmcnt), sliding window of row sums in registers (same eligibility) */
+                                        (LDS-DMA, counted vmcnt), sliding window of row sums in registers (same eligibility) */,
+    MI_BLUR_VARIANT_DIRECT = 4      /* no LDS: rows straight into registers, x-neighbours by DPP wave shifts (same eligibility) */
 } mi_blur_variant;
 
 const char *mi_blur_strerror(int status);
@@ -75,6 +77,8 @@ int mi_blur_version(void);
  *                      same time: fewer HBM re-reads), 0 = every band downwards
  *   "row_shuffle"      1 = x-neighbour bytes by DPP wave shifts (LDS only at wave/tile edges), 0 = from LDS (default)
  *   "prefer_stream"    1 = AUTO picks the streaming variant instead of the tiled one (default 0)
+ *   "prefer_direct"    AUTO and the direct (LDS-free) variant: 0 never | 1 (default) where it measured faster: every 5x5
+ *                      launch and 3x3 launches of up to 128 MiB of output | 2 for every eligible shape
  *   "stream_band_rows" streaming variant: output rows per wave (0 = chosen per launch)
  *   "ragged_tiled"     1 (default) = rows that are not a multiple of 16 bytes / unaligned pointers take the ragged form of the
  *                      tiled kernel; 0 = they take the generic one-byte-per-thread kernel

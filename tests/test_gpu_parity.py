@@ -53,6 +53,8 @@ def reset_opts(L):
     L.mi_blur_set_option(b"experiment", 0)
     L.mi_blur_set_option(b"stream_updown", 1)
     L.mi_blur_set_option(b"xcd_run", 0)
+    L.mi_blur_set_option(b"prefer_direct", 1)
+    L.mi_blur_set_option(b"direct_bh", 8)
 
 
 def want_batch(O, host, radius):
@@ -119,6 +121,48 @@ def test_stream_kernel_bit_exact(pkg, L, O, torch_cuda, h, w, c, radius):
                          {"stream_band_rows": 64, "xcd_remap": 1, "stream_updown": 1}):
                 got = gpu_blur(pkg, L, torch_cuda, host, radius, pkg.VARIANT_STREAM, opts=opts)
                 assert np.array_equal(got, want), f"{(got != want).sum()} bytes differ, opts={opts}"
+    finally:
+        reset_opts(L)
+
+
+@pytest.mark.parametrize("h,w,c", TILED_SHAPES)
+@pytest.mark.parametrize("radius", [1, 2])
+def test_direct_kernel_bit_exact(pkg, L, O, torch_cuda, h, w, c, radius):
+    """Direct variant (no LDS: rows straight into registers, x-neighbours by DPP wave shifts, 62 computing lanes per
+    wave): adversarial images, with and without the XCD map, output row ranges inside a band."""
+    n = 3
+    try:
+        for host in adversarial(O, h, w, c, n, h * 17 + w):
+            want = want_batch(O, host, radius)
+            for opts in ({"xcd_remap": 1}, {"xcd_remap": 0}):
+                got = gpu_blur(pkg, L, torch_cuda, host, radius, pkg.VARIANT_DIRECT, opts=opts)
+                assert np.array_equal(got, want), f"{(got != want).sum()} bytes differ, opts={opts}"
+        if h >= 4:
+            host = O.lcg_stream(n, h, w, c)
+            y0, y1 = 1, h - 1
+            got = gpu_blur(pkg, L, torch_cuda, host, radius, pkg.VARIANT_DIRECT, y0=y0, y1=y1)
+            assert np.array_equal(got, want_batch(O, host, radius)[:, y0:y1])
+    finally:
+        reset_opts(L)
+
+
+def test_direct_kernel_sizes_and_dispatch(pkg, L, O, torch_cuda):
+    """(1) Launch sizes around the wave / workgroup granularity of the flattened (image, band, chunk) space: 1..130 images
+    of a shape whose row is shorter than a wave, other band heights (C = 3 instantiations).  (2) AUTO takes the direct
+    kernel for 5x5 and for small 3x3 launches and the tiled kernel for big 3x3 ones — all three say the same bytes."""
+    try:
+        for n in (1, 2, 7, 61, 62, 63, 130):
+            host = O.lcg_stream(n, 9, 80, 3)
+            for radius in (1, 2):
+                want = want_batch(O, host, radius)
+                for bh in (8, 4, 12, 16):
+                    got = gpu_blur(pkg, L, torch_cuda, host, radius, pkg.VARIANT_DIRECT, opts={"direct_bh": bh})
+                    assert np.array_equal(got, want), (n, radius, bh)
+        host = O.lcg_stream(6, 256, 256, 3)
+        for radius in (1, 2):
+            want = want_batch(O, host, radius)
+            for pd in (0, 1, 2):
+                assert np.array_equal(gpu_blur(pkg, L, torch_cuda, host, radius, pkg.VARIANT_AUTO, opts={"prefer_direct": pd}), want), (radius, pd)
     finally:
         reset_opts(L)
 

@@ -20,6 +20,8 @@ def main():
         "5x5 tiled, rows/thread 8 (raw-window row pass: shipped)": "_ZN7mi_blur17blur_tiled_kernelILi3ELi2ELi8ELb1ELb0ELb0EEEvNS_11TiledParamsE",
         "5x5 tiled, rows/thread 8 (split-then-shift row pass: round-1 form)": "_ZN7mi_blur19blur_tiled_x_kernelILi3ELi2ELi8ELi0EEEvNS_11TiledParamsE",
         "5x5 streaming variant": "_ZN7mi_blur18blur_stream_kernelILi3ELi2EEEvNS_12StreamParamsE",
+        "3x3 direct (LDS-free), 8 rows per lane": "_ZN7mi_blur18blur_direct_kernelILi3ELi1ELi8EEEvNS_12DirectParamsE",
+        "5x5 direct (LDS-free), 8 rows per lane": "_ZN7mi_blur18blur_direct_kernelILi3ELi2ELi8EEEvNS_12DirectParamsE",
     }
     print("static counts per wave, gfx950, hipcc -O3 (C = 3); VALU per output dword = VALU / (8 rows x 4 dwords)")
     for label, sym in want.items():
