@@ -320,7 +320,7 @@ def main() -> None:
         n = max(tm["launches"], 1)
         us = tm["kernel_ms"] * 1e3 / n
         bpl = tm["bytes_alg"] / n
-        return {"workload": label, "launches_timed": int(n), "images_per_launch": batch, "launch_us": round(us, 2),
+        return {"workload": label, "kernel": L.mi_blur_last_kernel().decode(), "launches_timed": int(n), "images_per_launch": batch, "launch_us": round(us, 2),
                 "achieved_gbs": round(bpl / us / 1e3, 1) if us > 0 else 0.0, "frac": frac_of(bpl, us),
                 "img_s": round(per_pass * launches / wall, 1), "img_s_from_launch_us": round(batch / us * 1e6, 1) if us > 0 else 0.0}
 
@@ -351,7 +351,7 @@ def main() -> None:
         got = out.cpu().numpy()
         fnv = f"{L.mi_blur_fnv1a64(got.ctypes.data, got.size):016x}"           # tests/golden: d283787bcc5b6dfd (reference kernel)
         del band, out
-        return {"workload": "one 8192x8192x3 image per step, 3x3, one GPU (configs[4] at N=1)", "steps": steps,
+        return {"workload": "one 8192x8192x3 image per step, 3x3, one GPU (configs[4] at N=1)", "kernel": L.mi_blur_last_kernel().decode(), "steps": steps,
                 "step_us": round(us, 2), "achieved_gbs": round(2.0 * H * pitch / us / 1e3, 1), "frac": frac_of(2.0 * H * pitch, us),
                 "img_s": round(steps / wall, 1), "out_fnv": fnv}
 
@@ -439,6 +439,7 @@ def main() -> None:
             one_pass(time_every)
         torch.cuda.synchronize()
         local = time.perf_counter() - t0          # this rank's K steps, from the common (barrier + sync) start to its own drain;
+        dominant_kernel = L.mi_blur_last_kernel().decode()        # what the timed launches went to (the library's choice)
         if world > 1:                             # the closing barrier + sync follow, then MAX over ranks: the job's time is
             dist_barrier()                        # the slowest rank's, without the barrier's own latency added to every rank
             torch.cuda.synchronize()
@@ -632,6 +633,7 @@ def main() -> None:
         if world > 1:                             # the closing barrier + sync follow, then MAX over ranks: the job's time is
             dist_barrier()                        # the slowest rank's, without the barrier's own latency added to every rank
             torch.cuda.synchronize()
+        dominant_kernel = L.mi_blur_last_kernel().decode()
         elapsed = aggregate_max(local, dist if world > 1 else None, dev if backend == "nccl" else None)
         units = K
         value = units / elapsed
@@ -705,7 +707,7 @@ def main() -> None:
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": load_traffic(traffic_key) if (args.workload != "a1" or per_gpu_images == 5000) else None,
-                "kernel": "blur_fused_kernel" if fused else "blur_tiled_kernel", "algorithmic_bytes_per_launch": round(bytes_per_launch),
+                "kernel": dominant_kernel, "algorithmic_bytes_per_launch": round(bytes_per_launch),
                 "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches_timed": timed_n, "timing": timing_src}
     if args.workload != "a2":
         # With one launch per batch the launches of independent batches overlap on the GPU (one HIP stream each), so a

@@ -119,6 +119,7 @@ def lib() -> C.CDLL:
     sig = {
         "mi_blur_strerror": (C.c_char_p, [i]),
         "mi_blur_version": (i, []),
+        "mi_blur_last_kernel": (C.c_char_p, []),
         "mi_blur_device_count": (i, []),
         "mi_blur_set_option": (i, [C.c_char_p, i]),
         "mi_blur_enqueue": (i, [u8p, u8p, i, i, i, i, i, vp]),

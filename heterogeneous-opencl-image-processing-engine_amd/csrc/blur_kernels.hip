@@ -860,6 +860,9 @@ bool tiled_eligible(const void *in, const void *out, int width, int channels)
     return (pitch % 16 == 0) && ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0);
 }
 
+static thread_local const char *g_last_kernel = "";
+const char *last_kernel() { return g_last_kernel; }
+
 static inline int hip_status(hipError_t e) { return e == hipSuccess ? MI_BLUR_OK : MI_BLUR_ERR_HIP_BASE - (int)e; }
 
 template <typename K, typename P>
@@ -944,6 +947,8 @@ static int launch_fused_r(const LaunchDesc &d, const TiledParams &p, const Fused
 
 static int launch_tiled(const LaunchDesc &d, const Tunables &tun, bool ragged = false, const FusedDesc *fused = nullptr)
 {
+    if (!(fused && fused->geometry_only))
+        g_last_kernel = fused ? "blur_fused_kernel" : (d.max_blocks > 0 && !ragged ? "blur_tiled_loop_kernel" : "blur_tiled_kernel");
     const int R = d.radius;
     const int pitch = d.width * d.channels, cpr = (pitch + 15) / 16, rows = d.y1 - d.y0;   // ragged: last chunk partial
     // Output rows per thread.  8 amortises the 2R priming rows of the sliding window best when the grid is
@@ -1028,6 +1033,7 @@ int launch_fused(const LaunchDesc &d, const FusedDesc &f)
 
 static int launch_stream(const LaunchDesc &d, const Tunables &tun)
 {
+    g_last_kernel = "blur_stream_kernel";
     const int pitch = d.width * d.channels, cpr = pitch / 16, rows = d.y1 - d.y0;
     StreamParams p{};
     p.in = d.in; p.out = d.out;
@@ -1100,6 +1106,7 @@ static int launch_direct(const LaunchDesc &d, const Tunables &tun)
 template <int BH>
 static int launch_direct_bh(const LaunchDesc &d, const Tunables &tun)
 {
+    g_last_kernel = "blur_direct_kernel";
     const int pitch = d.width * d.channels, cpr = pitch / 16, rows = d.y1 - d.y0;
     DirectParams p{};
     p.in = d.in; p.out = d.out;
@@ -1133,6 +1140,7 @@ static int launch_direct_bh(const LaunchDesc &d, const Tunables &tun)
 
 static int launch_generic(const LaunchDesc &d)
 {
+    g_last_kernel = "blur_generic_kernel";
     GenericParams p{};
     const int pitch = d.width * d.channels, rows = d.y1 - d.y0;
     p.in = d.in; p.out = d.out;

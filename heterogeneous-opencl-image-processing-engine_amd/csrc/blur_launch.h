@@ -44,6 +44,9 @@ int launch_fused(const LaunchDesc &d, const FusedDesc &f);
 int launch_planar_to_interleaved(const uint8_t *src, uint8_t *dst, int width, int height, int channels, int n_images, hipStream_t s);
 int launch_interleaved_to_planar(const uint8_t *src, uint8_t *dst, int width, int height, int channels, int n_images, hipStream_t s);
 
+// Name of the kernel the calling thread's most recent launch() / launch_fused() chose ("" before the first).
+const char *last_kernel();
+
 // True when the LDS-tiled vector kernel can take this shape.
 bool tiled_eligible(const void *in, const void *out, int width, int channels);
 

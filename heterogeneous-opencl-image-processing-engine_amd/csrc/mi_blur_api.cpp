@@ -67,6 +67,8 @@ extern "C" const char *mi_blur_strerror(int status)
 
 extern "C" int mi_blur_version(void) { return MI_BLUR_VERSION; }
 
+extern "C" const char *mi_blur_last_kernel(void) { return last_kernel(); }
+
 extern "C" int mi_blur_device_count(void)
 {
     int n = 0;

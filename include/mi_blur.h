@@ -62,6 +62,10 @@ typedef enum mi_blur_variant {
 
 const char *mi_blur_strerror(int status);
 int mi_blur_version(void);
+/* Which kernel the calling thread's most recent launch went to ("blur_tiled_kernel", "blur_direct_kernel",
+ * "blur_fused_kernel", "blur_tiled_loop_kernel", "blur_stream_kernel", "blur_generic_kernel"; "" before the first):
+ * reports name the kernel a profiler will show.  Static string, never NULL. */
+const char *mi_blur_last_kernel(void);
 
 /* Kernel tuning knobs (A/B benching and tests; defaults are the shipped configuration).  PROCESS-WIDE: a call
  * publishes a new set of knobs that every launch issued afterwards (by any context, any thread) takes a coherent

@@ -163,6 +163,9 @@ def test_direct_kernel_sizes_and_dispatch(pkg, L, O, torch_cuda):
             want = want_batch(O, host, radius)
             for pd in (0, 1, 2):
                 assert np.array_equal(gpu_blur(pkg, L, torch_cuda, host, radius, pkg.VARIANT_AUTO, opts={"prefer_direct": pd}), want), (radius, pd)
+                assert L.mi_blur_last_kernel() == (b"blur_tiled_kernel" if pd == 0 else b"blur_direct_kernel")
+        assert np.array_equal(gpu_blur(pkg, L, torch_cuda, O.lcg_stream(1, 33, 17, 3), 1, pkg.VARIANT_AUTO), want_batch(O, O.lcg_stream(1, 33, 17, 3), 1))
+        assert L.mi_blur_last_kernel() == b"blur_tiled_kernel"          # ragged rows: the tiled kernel's ragged form
     finally:
         reset_opts(L)
 
