@@ -46,6 +46,11 @@
 // bytes (copies of the last pixel) behind them, so no lane synthesises the right clamp; outputs are unaligned
 // 16-byte stores, the partial chunk a masked 8/4/2/1-byte store of the bytes that exist.
 //
+// Direct kernel (blur_direct_kernel): the same row-stream arithmetic with no LDS at all — every lane loads the 8 + 2R rows
+// of its own chunk column straight into registers (all requests in flight at once, consumed row by row under the
+// compiler's counted vmcnt), takes its x-neighbours' bytes from the adjacent lanes by DPP wave shifts, 62 computing lanes
+// per wave.  AUTO's choice for 5x5 and for 3x3 launches that do not fill the chip for long; big 3x3 launches stay tiled.
+//
 // Generic kernel: one output byte per thread, any shape (rows shorter than 16 bytes, more than 4
 // channels).  Correct everywhere, fast nowhere.
 #include "blur_launch.h"
@@ -838,11 +843,14 @@ void set_tunables(const Tunables &t)
 unsigned long long *debug_xcd_buffer()
 {
     static unsigned long long *buf = nullptr;
+    static int buf_device = -1;
     static std::once_flag once;
     std::call_once(once, [] {
-        if (hipMalloc((void **)&buf, (size_t)XCD_DEBUG_SLOTS * 16) != hipSuccess) { (void)hipGetLastError(); buf = nullptr; }
+        if (hipGetDevice(&buf_device) != hipSuccess || hipMalloc((void **)&buf, (size_t)XCD_DEBUG_SLOTS * 16) != hipSuccess) { (void)hipGetLastError(); buf = nullptr; }
         else (void)hipMemset(buf, 0, (size_t)XCD_DEBUG_SLOTS * 16);
     });
+    int dev = -1;                                    // the slots live on the device that was current at first use: launches on
+    if (hipGetDevice(&dev) != hipSuccess || dev != buf_device) { (void)hipGetLastError(); return nullptr; }   // another device get none
     return buf;
 }
 unsigned debug_xcd_slots() { return XCD_DEBUG_SLOTS; }

@@ -446,8 +446,9 @@ static int submit_common(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_o
         // Zero-copy: when both caller buffers are pinned the kernel reads and writes them in place over PCIe.  On this
         // platform one kernel moving both directions sustains ~70 GB/s (35 each way) while the copy engines give ~55 GB/s
         // one way at a time and collapse to ~28 GB/s total when H2D and D2H overlap (profiles/r01_zero_copy.txt): +33-40 %
-        // images/s end to end.  Zero-copy launches of one context share one in-order stream — two of them in flight at once
-        // halve the link rate just like two copies do.
+        // images/s end to end.  Each zero-copy launch keeps only "zero_copy_blocks" workgroups resident (they loop over the
+        // tiles) and consecutive launches alternate over up to "zero_copy_streams" of the context's streams, so that reads
+        // of one tile and writes of another keep both directions of the link busy (profiles/r02_e2e.txt).
         if (tunables().zero_copy) {   // (a copy of the knobs as they are now)
             const uint8_t *zin = pinned_device_ptr(host_in);
             uint8_t *zout = pinned_device_ptr(host_out);
@@ -455,7 +456,7 @@ static int submit_common(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_o
             if (zin && zout && (dense || (tiled_eligible(zin, zout, c->W, c->C) && in_stride % 16 == 0 && out_stride % 16 == 0))) {
                 s.out_staged = false; s.user_out = host_out; s.out_bytes = out_bytes; s.out_band = band_out; s.out_stride = out_stride;
                 s.out_n = n_images;
-                // all zero-copy launches of a context share one in-order stream, unless "zero_copy_streams" says 2
+                // consecutive zero-copy launches alternate over the first zn streams of the context
                 const int zn = std::max(1, std::min(tunables().zero_copy_streams, (int)c->slots.size()));
                 const hipStream_t zs = c->slots[(c->zero_copy_launches % (uint64_t)zn)].stream;
                 // one dispatch packet, nothing else: the kernel's own stop event doubles as the completion event (every
