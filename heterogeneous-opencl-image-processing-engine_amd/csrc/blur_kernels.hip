@@ -497,7 +497,9 @@ __global__ __launch_bounds__(256) void blur_tiled_x_kernel(const TiledParams p)
 }
 
 // Fused stream: ONE dispatch for a whole pass of the resident stream, with the batch kept as the unit of completion.
-// Blocks are ordered batch by batch (XCD-contiguous inside a batch's window of tiles); every wave, once its own output
+// Blocks are ordered window by window — a window is 8 consecutive batches ("fused_window"), XCD-contiguous inside it, so
+// each XCD blurs one whole batch (35 whole images) per window: 2 % faster than batch-by-batch order, where every batch is
+// cut into eight 35-tile pieces (profiles/r02_fused_window.txt) — and every tile counts into its own batch; every wave, once its own output
 // stores have drained, meets the rest of its block at a barrier; one thread then adds 1 to the batch's counter with a
 // fire-and-forget atomic (one of 8 per batch).  The host reads the counters: a batch is complete when they sum to its
 // number of blocks.  A consumer
@@ -507,23 +509,31 @@ struct FusedParams {
     unsigned *count;          // device, EIGHT counters per batch (spread by block number: less contention), zeroed before the launch
     unsigned tiles_per_batch; // batch_images * tiles per image
     int release;              // 1 = release-ordered completion add (agent scope): the architectural form, ~6x slower
+    unsigned window;          // batches per window of the blockIdx -> tile map (>= 1)
 };
 
 template <int C, int R, int RPG>
 __global__ __launch_bounds__(256) void blur_fused_kernel(const TiledParams p, const FusedParams f)
 {
-    const unsigned b = blockIdx.x / f.tiles_per_batch, base = b * f.tiles_per_batch;
-    const unsigned nb = min(f.tiles_per_batch, p.nblocks - base);          // the last batch may be short
+    // Blocks are taken window by window; a window is `window` consecutive batches and its tiles are dealt so that each XCD
+    // gets one contiguous eighth of it (with 8 batches per window: one whole batch per XCD, i.e. 35 whole images whose
+    // tile-edge rows stay in that XCD's L2).  Every tile is counted into ITS batch, so the batch stays the unit of
+    // completion; the batches of a window finish at about the same time, windows in stream order.
+    const unsigned tpw = f.tiles_per_batch * f.window;
+    const unsigned wnd = blockIdx.x / tpw, base = wnd * tpw;
+    const unsigned nw = min(tpw, p.nblocks - base);                          // the last window may be short
     const unsigned w = blockIdx.x - base;
-    tiled_tile<C, R, RPG, true, false, false, true>(p, base + (nb >= 16 ? xcd_map(w, nb, p.xcd) : w));
+    const unsigned tile = base + (nw >= 16 ? xcd_map(w, nw, p.xcd) : w);
+    const unsigned b = tile / f.tiles_per_batch;
+    tiled_tile<C, R, RPG, true, false, false, true>(p, tile);
     // Outputs were written THROUGH L2 (the XCDs' L2s are not coherent with each other), so once this wave's stores
     // have drained they are in memory.  No device-scope release fence (an L2 write-back per call: 15x the whole pass when
     // every block does one), no returning atomic (its round trip would keep the block's LDS allocated).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                       // every wave of the block has drained (one atomic per block: the counters are hot spots)
     if (threadIdx.x == 0) {
-        if (f.release) __hip_atomic_fetch_add(&f.count[b * 8u + (w & 7u)], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        else __hip_atomic_fetch_add(&f.count[b * 8u + (w & 7u)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f.release) __hip_atomic_fetch_add(&f.count[b * 8u + ((w ^ (w >> 3)) & 7u)], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_fetch_add(&f.count[b * 8u + ((w ^ (w >> 3)) & 7u)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -818,7 +828,7 @@ static std::mutex &tunables_mutex() { static std::mutex m; return m; }
 static Tunables &tunables_storage()
 {
     static Tunables t = [] {
-        Tunables v{1, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0, 4, 24, 1, 1, 8, 0};  // rpg 0 / stream_bh 0 = choose per launch
+        Tunables v{1, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0, 4, 24, 1, 1, 8, 0, 8};  // rpg 0 / stream_bh 0 = choose per launch
         if (const char *e = getenv("MI_BLUR_STAGE")) v.stage_dma = strcmp(e, "reg") != 0;
         if (const char *e = getenv("MI_BLUR_RPG")) { const int r = atoi(e); v.rpg = (r == 4 || r == 8 || r == 16) ? r : 0; }
         if (const char *e = getenv("MI_BLUR_XCD")) v.xcd_remap = atoi(e) != 0;
@@ -1015,6 +1025,7 @@ static int launch_tiled(const LaunchDesc &d, const Tunables &tun, bool ragged = 
         FusedParams f{};
         f.count = fused->count;
         f.release = tun.fused_release;
+        f.window = (unsigned)std::max(1, tun.fused_window);
         const long long tpb = (long long)fused->batch_images * p.ntiles_y * p.nstrips;
         if (tpb <= 0 || tpb > 0x7fffffffLL) return MI_BLUR_ERR_INVALID;
         f.tiles_per_batch = (unsigned)tpb;

@@ -67,6 +67,7 @@ struct Tunables {
                          // (every 5x5 launch, 3x3 launches up to 128 MiB of output), 2 whenever the shape is eligible
     int direct_bh;       // direct variant: output rows per lane (8; 4 | 12 | 16 instantiated for C = 3 only, A/B runs)
     int debug_xcd_times; // diagnostics: the tiled kernel's workgroups leave start/end times per XCD (mi_blur_debug_xcd_times)
+    int fused_window;    // fused stream: batches per window of its blockIdx -> tile map (8: one whole batch per XCD per window)
 };
 Tunables tunables();
 unsigned long long *debug_xcd_buffer();

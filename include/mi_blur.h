@@ -94,6 +94,9 @@ const char *mi_blur_last_kernel(void);
  *                      flight; a launch that puts every tile on the chip at once reads everything, then writes
  *                      everything (half duplex).  4 x 24 workgroups, each on its own read/compute/write cycle, keep both
  *                      directions busy: +10-18 % images/s end to end (profiles/r02_e2e.txt)
+ *   "fused_window"     8 (default): the fused stream takes its tiles window by window, a window being this many consecutive
+ *                      batches dealt over the XCDs (8 = one whole batch per XCD); the batches of a window complete at about
+ *                      the same time, windows in stream order.  1 = batch by batch
  *   "fused_release"    0 (default) | 1: how a block of the fused stream publishes "my outputs are in memory" — see
  *                      mi_blur_resident_run_fused */
 int mi_blur_set_option(const char *key, int value);
@@ -243,7 +246,7 @@ void mi_blur_timed_coverage(mi_blur_ctx *ctx, uint64_t *launches, uint64_t *byte
 
 /* The same pass as ONE dispatch ("fused stream").  A batch-35 stream issued launch by launch is bound by the
  * GPU's per-dispatch processing (~3.5 us each over 4 hardware queues), not by the kernel; here the kernel walks
- * the batches itself — blocks ordered batch by batch — and every wave counts itself into its batch's counter once
+ * the batches itself — blocks ordered in windows of 8 batches, in stream order — and every workgroup counts itself into its batch's counter once
  * its outputs are in memory.  The batch stays the unit of COMPLETION (mi_blur_resident_batches_done reads the
  * counters and returns how many leading batches have their outputs ready, without waiting for the dispatch, which
  * may still be running) without being the unit of DISPATCH.  n_images <= pool size (one contiguous run of the pool); aligned tiled shapes only

@@ -912,7 +912,8 @@ def test_fused_stream_batches_are_readable_as_soon_as_counted(pkg, L, O, torch_c
 
 
 def test_fused_stream_release_mode_and_geometry_change(pkg, L, O, torch_cuda):
-    """(1) "fused_release" 1 — the architectural (release-ordered) completion add — gives the same pixels and counts.
+    """(0) Windows of 1, 3, 8 and more batches than the stream has: same pixels, every batch counted in.
+    (1) "fused_release" 1 — the architectural (release-ordered) completion add — gives the same pixels and counts.
     (2) Same-shape passes keep the counters counting up; a knob that changes the launch geometry between two such passes
     (rows per thread 4 -> 8: half as many blocks per batch) must zero them instead of leaving the count unreachable."""
     h, w, c, r, n, batch = 64, 128, 3, 1, 120, 16
@@ -922,18 +923,20 @@ def test_fused_stream_release_mode_and_geometry_change(pkg, L, O, torch_cuda):
         with pkg.Context(0, w, h, c, r, max_batch=1, n_slots=1) as ctx:
             ctx.resident_alloc(n)
             ctx.resident_fill_synthetic(3)
-            for rpt, rel in ((4, 0), (4, 0), (8, 0), (8, 1), (4, 1), (0, 0)):
+            for rpt, rel, win in ((4, 0, 8), (4, 0, 8), (8, 0, 8), (8, 1, 1), (4, 1, 3), (0, 0, 1), (0, 0, 100)):
                 pkg.check(L.mi_blur_set_option(b"rows_per_thread", rpt))
                 pkg.check(L.mi_blur_set_option(b"fused_release", rel))
+                pkg.check(L.mi_blur_set_option(b"fused_window", win))
                 ctx.resident_run_fused(n, batch)
-                assert ctx.wait_batches(nb, timeout_s=30.0) == nb, (rpt, rel)
+                assert ctx.wait_batches(nb, timeout_s=30.0) == nb, (rpt, rel, win)
                 ctx.sync()
                 out = np.zeros_like(want)
                 ctx.resident_download(0, out.ctypes.data, n)
-                assert np.array_equal(out, want), (rpt, rel)
+                assert np.array_equal(out, want), (rpt, rel, win)
     finally:
         pkg.check(L.mi_blur_set_option(b"rows_per_thread", 0))
         pkg.check(L.mi_blur_set_option(b"fused_release", 0))
+        pkg.check(L.mi_blur_set_option(b"fused_window", 8))
 
 
 def test_batches_done_reports_errors_as_negative_status(pkg, L):
