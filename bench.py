@@ -301,28 +301,37 @@ def main() -> None:
     # ------------------------------------------------------------------------------------------------------------
     # secondary points (N=1 only, outside the timed region).  Each is a small self-contained measurement.
     # ------------------------------------------------------------------------------------------------------------
-    def point_resident(w, h, c, radius, pool, per_pass, batch, launches, label) -> dict:
-        """`launches` back-to-back passes of a resident pool, every dispatch timestamped."""
-        ctx = pkg.Context(local_rank, w, h, c, radius, max_batch=1, n_slots=1)
-        ctx.resident_alloc(pool); ctx.resident_fill_synthetic(0)
-        warm_until = time.perf_counter() + SECONDARY_WARM_S        # filling the pool left the GPU idle: ramp the clock again
-        while time.perf_counter() < warm_until:
-            for _ in range(10):
-                ctx.resident_run(per_pass, batch)
-            ctx.sync()
-        ctx.reset_timing()
-        t0 = time.perf_counter()
-        for _ in range(launches):
-            ctx.resident_run(per_pass, batch, timed=1)
-        tm = ctx.sync()
-        wall = time.perf_counter() - t0
-        ctx.close()
-        n = max(tm["launches"], 1)
-        us = tm["kernel_ms"] * 1e3 / n
-        bpl = tm["bytes_alg"] / n
-        return {"workload": label, "kernel": L.mi_blur_last_kernel().decode(), "launches_timed": int(n), "images_per_launch": batch, "launch_us": round(us, 2),
+    def point_resident(w, h, c, radius, pool, per_pass, batch, launches, label, allocations=3) -> dict:
+        """`launches` back-to-back passes of a resident pool, every dispatch timestamped — on `allocations` fresh pools: where
+        the buffers happen to lie moves this kernel between two levels 6 % apart (profiles/r02_allocation_placement.txt), so
+        the point is the MEDIAN allocation and every allocation's figure is listed."""
+        runs = []
+        keep = []                                                  # held until the end so that each pool is a new allocation
+        for _ in range(allocations):
+            ctx = pkg.Context(local_rank, w, h, c, radius, max_batch=1, n_slots=1)
+            ctx.resident_alloc(pool); ctx.resident_fill_synthetic(0)
+            warm_until = time.perf_counter() + SECONDARY_WARM_S    # filling the pool left the GPU idle: ramp the clock again
+            while time.perf_counter() < warm_until:
+                for _ in range(10):
+                    ctx.resident_run(per_pass, batch)
+                ctx.sync()
+            ctx.reset_timing()
+            t0 = time.perf_counter()
+            for _ in range(launches):
+                ctx.resident_run(per_pass, batch, timed=1)
+            tm = ctx.sync()
+            wall = time.perf_counter() - t0
+            n = max(tm["launches"], 1)
+            runs.append((tm["kernel_ms"] * 1e3 / n, tm["bytes_alg"] / n, per_pass * launches / wall, int(n)))
+            keep.append(ctx)
+        kernel = L.mi_blur_last_kernel().decode()
+        for ctx in keep:
+            ctx.close()
+        us, bpl, img_s, n = sorted(runs)[len(runs) // 2]
+        return {"workload": label, "kernel": kernel, "launches_timed": n, "images_per_launch": batch, "launch_us": round(us, 2),
+                "launch_us_by_allocation": [round(r[0], 2) for r in runs],
                 "achieved_gbs": round(bpl / us / 1e3, 1) if us > 0 else 0.0, "frac": frac_of(bpl, us),
-                "img_s": round(per_pass * launches / wall, 1), "img_s_from_launch_us": round(batch / us * 1e6, 1) if us > 0 else 0.0}
+                "img_s": round(img_s, 1), "img_s_from_launch_us": round(batch / us * 1e6, 1) if us > 0 else 0.0}
 
     def point_a2_1gpu(steps) -> dict:
         """configs[4] at N=1: the whole 8192x8192x3 image as one band launch (no exchange partner: both edges clamp)."""
