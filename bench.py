@@ -32,9 +32,17 @@ clGetEventProfilingInfo, heterogeneous_blur.c:567-577); peak = 8 TB/s HBM3E.
 `cpu_baseline`: the oracle (kind "port": scalar per-pixel restatement of gaussian_kernel.cl,
 what an OpenCL CPU device executes) on all host cores, rank 0 at N=1 only, bounded sample.
 At N=1 the a1 line also carries, measured after the timed region: `sustained_img_s` (>= 1 s of back-to-back passes),
-`per_batch_launches` (the same stream as 143 launches per pass), and `extra` = {one_launch_5000_images, hd1080_5x5
-(configs[2]), a2_8192_1gpu (configs[4] at N=1), e2e_pcie_inclusive (host buffers in -> host buffers out, batch 35
-and 500; comparable to the reference's wall clock, never `value`)}.
+`per_batch_launches` (the same stream as 143 launches per pass), `batch_completion_us` (when the host SEES batch k of the
+fused pass complete: first / p50 / last batch, polled during >= 24 passes — the per-batch clFinish of
+heterogeneous_blur.c:538-539), `release_mode_us` (the same pass with the architectural release-ordered completion add), and
+`extra` = {one_launch_5000_images, hd1080_5x5 (configs[2]), a2_8192_1gpu (configs[4] at N=1), e2e_pcie_inclusive (host
+buffers in -> host buffers out, batch 35 and 500; comparable to the reference's wall clock, never `value`)}.
+At N>1 the a1 line carries BOTH multi-GPU configs: configs[3] is `value`; after its timed region the same ranks run
+configs[4] (`extra.a2_8192_rowsplit`: the 8192x8192x3 image row-split over the N GPUs, halo rows by RCCL send/recv, the
+plain step and the overlapped step both timed, `rccl_ranks` from the communicator).
+`parity`: every output image of every rank's shard (a1) and every rank's band of the 8192^2 output (a2) is hashed
+(FNV-1a-64) and compared with tests/golden (hashes of the UNMODIFIED reference kernel's output, tests/golden/make_golden.py);
+a mismatch on any rank fails the job (exit 3) instead of printing a line.
 """
 from __future__ import annotations
 
@@ -89,6 +97,63 @@ def load_traffic(workload: str):
         return None
 
 
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def load_golden() -> dict:
+    """tests/golden/blur_golden.json (+ the per-image hashes of the 50 000-image stream): reference-kernel outputs as data."""
+    with open(os.path.join(GOLDEN_DIR, "blur_golden.json")) as f:
+        g = json.load(f)
+    try:
+        import numpy as np
+        g["_stream50k_image_fnv"] = np.load(os.path.join(GOLDEN_DIR, g["stream50k"]["file"]))
+    except (KeyError, OSError):
+        g["_stream50k_image_fnv"] = None
+    return g
+
+
+def hash_images(L, host, n: int, image_bytes: int, threads: int):
+    """FNV-1a-64 of each of n images laid end to end in the numpy buffer `host` (ctypes releases the GIL)."""
+    import numpy as np
+    out = np.empty(n, dtype=np.uint64)
+    base = host.ctypes.data
+    threads = max(1, min(threads, n))
+
+    def work(b, e):
+        for i in range(b, e):
+            out[i] = L.mi_blur_fnv1a64(base + i * image_bytes, image_bytes)
+
+    th = [threading.Thread(target=work, args=(n * t // threads, n * (t + 1) // threads)) for t in range(threads)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    return out
+
+
+def verify_resident_stream(pkg, L, ctx, first_index: int, n_images: int, image_bytes: int, golden: dict, threads: int) -> dict:
+    """Download EVERY output image of the resident pool and compare its hash with the reference kernel's
+    (tests/golden/stream50k_image_fnv.npy, image i of the LCG stream).  Returns {checked, mismatches, first_bad, seconds}."""
+    import numpy as np
+    gold = golden.get("_stream50k_image_fnv")
+    if gold is None or first_index + n_images > len(gold):
+        return {"checked": 0, "mismatches": 0, "note": "no golden hashes for this range"}
+    t0 = time.perf_counter()
+    chunk = max(1, min(n_images, (256 << 20) // image_bytes))
+    host = np.empty(chunk * image_bytes, np.uint8)
+    bad, first_bad = 0, None
+    for i in range(0, n_images, chunk):
+        m = min(chunk, n_images - i)
+        ctx.resident_download(i, host.ctypes.data, m)
+        got = hash_images(L, host, m, image_bytes, threads)
+        ne = np.nonzero(got != gold[first_index + i:first_index + i + m])[0]
+        if len(ne):
+            bad += len(ne)
+            if first_bad is None:
+                first_bad = first_index + i + int(ne[0])
+    return {"checked": n_images, "mismatches": int(bad), "first_bad": first_bad, "seconds": round(time.perf_counter() - t0, 2)}
+
+
 def effective_cpus() -> int:
     """CPUs this process can actually run on: the affinity mask capped by the cgroup CPU quota (a 1-GPU box shows all
     of the host's hardware threads in the mask but grants a 16-CPU share)."""
@@ -108,51 +173,93 @@ def effective_cpus() -> int:
     return n
 
 
-def cpu_baseline(n_target: int, h: int, w: int, c: int, radius: int) -> dict:
-    """Oracle (scalar per-pixel restatement) on the host cores this process may use; ~10 s of wall clock."""
-    O = entry.load_oracle()
-    cores = effective_cpus()
-    lib = O.lib()
-    probe = O.lcg_stream(8, h, w, c)
-    out = probe.copy()
-    t0 = time.perf_counter()
-    lib.oracle_blur_batch(probe.ctypes.data, out.ctypes.data, w, h, c, radius, 8)
-    per_img = (time.perf_counter() - t0) / 8
-    n = int(min(n_target, max(cores * 4, 12.0 * cores / per_img)))     # ~12 s wall
+def cpu_baseline(n_target: int, h: int, w: int, c: int, radius: int, batch: int = 35) -> dict:
+    """The CPU path timed beside the GPU on this box's host cores, every leg in the reference's batch-loop
+    shape: per batch, build the batch buffer from the stream (the replicate memcpy of heterogeneous_blur.c:439-442, which
+    the reference times, :415,603), then blur it.
+      value               oracle port (scalar per-pixel C restatement of gaussian_kernel.cl — what an OpenCL CPU device
+                          executes), one thread per usable CPU, each looping over its own batches
+      one_thread          the same port on ONE thread
+      product_cpu_device  mi_blur_cpu_run per batch (the hosts' `cpu` device: what `./heterogeneous_blur cpu`,
+                          BASELINE configs[0], executes), on min(cores, 16) threads and on one
+      reference_kernel    the UNMODIFIED reference kernel (oracle/_ref) when it travelled here, smaller sample
+    ~20-25 s of wall clock in total."""
     import numpy as np
-    src = np.empty((n, h, w, c), np.uint8)
+    O = entry.load_oracle()
     pkg = entry.load_package()
-    pkg.lib().mi_blur_fill_synthetic(src.ctypes.data, w, h, c, 0, n, cores)
-    dst = np.empty_like(src)
-    dst[:] = 0                                                          # touch pages outside the timed part
-    bounds = [(n * i // cores, n * (i + 1) // cores) for i in range(cores)]
-
+    L = pkg.lib()
+    olib = O.lib()
+    cores = effective_cpus()
     isz = h * w * c
+    batch = max(1, min(batch, n_target))
 
-    def work(b, e):
-        if e > b:
-            lib.oracle_blur_batch(src[b:e].ctypes.data, dst[b:e].ctypes.data, w, h, c, radius, e - b)
-
+    probe = O.lcg_stream(4, h, w, c)
+    pout = probe.copy()
+    olib.oracle_blur_batch(probe.ctypes.data, pout.ctypes.data, w, h, c, radius, 4)          # first touch / code load
     t0 = time.perf_counter()
-    work(0, min(n, 4))                                                    # steady-state cost (the probe above paid first-touch)
-    per_img = max(per_img, (time.perf_counter() - t0) / min(n, 4))
-    reps = int(max(1, min(64, round(8.0 * cores / (per_img * n)))))       # ~8-12 s of wall clock whatever the core count
+    olib.oracle_blur_batch(probe.ctypes.data, pout.ctypes.data, w, h, c, radius, 4)
+    per_img = max((time.perf_counter() - t0) / 4, 1e-6)
+    n = int(min(n_target, max(cores * batch, 6.0 * cores / per_img)))                        # ~6 s on all cores
+    src = np.empty((n, h, w, c), np.uint8)
+    L.mi_blur_fill_synthetic(src.ctypes.data, w, h, c, 0, n, cores)
 
-    def work_reps(b, e):
+    def batch_loop(blur, b, e, reps):
+        """The reference's loop over [b, e): batch buffer built inside the timed region, then blurred."""
+        bin_, bout = np.empty(batch * isz, np.uint8), np.zeros(batch * isz, np.uint8)
         for _ in range(reps):
-            work(b, e)
+            for s0 in range(b, e, batch):
+                m = min(batch, e - s0)
+                C.memmove(bin_.ctypes.data, src.ctypes.data + s0 * isz, m * isz)               # heterogeneous_blur.c:439-442
+                blur(bin_.ctypes.data, bout.ctypes.data, m)
 
-    th = [threading.Thread(target=work_reps, args=be) for be in bounds]
-    t0 = time.perf_counter()
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    dt = time.perf_counter() - t0
+    def port(pin, pout_, m):
+        olib.oracle_blur_batch(pin, pout_, w, h, c, radius, m)
+
+    def timed_threads(blur, n_img, threads, reps):
+        th = [threading.Thread(target=batch_loop, args=(blur, n_img * i // threads, n_img * (i + 1) // threads, reps))
+              for i in range(threads)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return time.perf_counter() - t0
+
+    reps = int(max(1, min(64, round(6.0 * cores / (per_img * n)))))
+    dt = timed_threads(port, n, cores, reps)
     res = {"value": round(n * reps / dt, 2), "unit": "img/s", "cores": cores, "kind": "port",
-           "sample": f"{reps} pass(es) over {n} of the same synthetic {w}x{h}x{c} images, radius {radius}, "
-                     f"oracle_blur_batch (scalar per-pixel C restatement) on {cores} threads "
-                     f"(affinity mask {len(os.sched_getaffinity(0))}, cgroup quota applied), {dt:.1f} s wall"}
+           "sample": f"{reps} pass(es) over {n} of the same synthetic {w}x{h}x{c} images in batches of {batch}, radius {radius}: per batch "
+                     f"memcpy into the batch buffer + oracle_blur_batch (scalar per-pixel C restatement), {cores} threads each on its own "
+                     f"batches (affinity mask {len(os.sched_getaffinity(0))}, cgroup quota applied), {dt:.1f} s wall"}
+    n1 = int(max(batch, min(n, 3.5 / per_img)))
+    dt1 = timed_threads(port, n1, 1, 1)
+    res["one_thread"] = {"value": round(n1 / dt1, 2), "unit": "img/s", "cores": 1,
+                         "sample": f"{n1} images, same loop on one thread, {dt1:.1f} s wall"}
+
+    # the product's own cpu device (separable, vectorised; a named device, never a fallback): one call per batch
+    nt = min(cores, 16)
+
+    def product(threads):
+        def blur(pin, pout_, m):
+            pkg.check(L.mi_blur_cpu_run(pin, pout_, w, h, c, radius, m, threads), "mi_blur_cpu_run")
+        blur(probe.ctypes.data, pout.ctypes.data, 4)                                              # worker pool start-up
+        batch_loop(blur, 0, min(n, 8 * batch), 1)                                               # page in, spin the pool up
+        t0 = time.perf_counter()
+        batch_loop(blur, 0, min(n, 8 * batch), 1)
+        est = max((time.perf_counter() - t0) / min(n, 8 * batch), 1e-7)
+        m_img = int(max(batch, min(n, 2.5 / est)))
+        r = int(max(1, min(64, round(2.5 / (est * m_img)))))
+        t0 = time.perf_counter()
+        batch_loop(blur, 0, m_img, r)
+        d = time.perf_counter() - t0
+        return {"value": round(m_img * r / d, 2), "unit": "img/s", "cores": threads,
+                "sample": f"{r} pass(es) over {m_img} images, per batch of {batch}: memcpy into the batch buffer + mi_blur_cpu_run on {threads} thread(s), {d:.1f} s wall"}
+
+    pr = product(nt)
+    pr["what"] = "the hosts' `cpu` device (what `./heterogeneous_blur cpu`, BASELINE configs[0], executes)"
+    pr["one_thread"] = product(1)
+    res["product_cpu_device"] = pr
+
     # Beside it, when the build container's oracle/_ref travelled here: the UNMODIFIED reference kernel
     # (gaussian_kernel.cl compiled for x86-64 by oracle/Makefile, one call per work-item of the padded NDRange; 3x3 only),
     # on a smaller sample.  It is slower than the port (its min/max/get_global_id are out-of-line calls), so the port
@@ -160,6 +267,7 @@ def cpu_baseline(n_target: int, h: int, w: int, c: int, radius: int) -> dict:
     if radius == 1 and O.ref_available():
         rlib = O.ref()
         m = int(min(n, max(cores, 3.0 * cores / (per_img * 3.0))))
+        dst = np.empty((m, h, w, c), np.uint8)
 
         def rwork(b, e):
             for i in range(b, e):
@@ -239,6 +347,8 @@ def main() -> None:
     ap.add_argument("--ramp-seconds", type=float, default=0.5,
                     help="untimed passes before the warm-up steps, so the timed region runs at the sustained clock")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the check of every output image / band against tests/golden (reference-kernel hashes)")
     ap.add_argument("--extra", action="store_true", help="(default at N=1; kept for old command lines)")
     ap.add_argument("--no-extra", action="store_true",
                     help="N=1 a1: skip the points measured after the timed region (sustained, per-batch launches, hd5, 8192^2, e2e)")
@@ -389,12 +499,194 @@ def main() -> None:
         e2e.close()
         return res
 
+    golden = load_golden()
+    hash_threads = max(1, min(16, effective_cpus() // max(world, 1)))
+
+    def check_parity(results: dict) -> None:
+        """Every rank brings {name: {"ok": bool, ...}}; ANY mismatch on ANY rank fails the whole job (exit 3, no JSON line)."""
+        bad = [k for k, v in results.items() if not v.get("ok", False)]
+        flag = torch.tensor([len(bad)], dtype=torch.int64, device=dev if (world > 1 and backend == "nccl") else "cpu")
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+        if bad:
+            print(f"bench.py: rank {rank}: PARITY FAILURE vs tests/golden (reference kernel): "
+                  + "; ".join(f"{k}: {results[k]}" for k in bad), file=sys.stderr, flush=True)
+        if int(flag.item()) > 0:
+            if world > 1:
+                dist.destroy_process_group()
+            raise SystemExit(3)
+
+    def run_a2(K2: int, W2: int, ramp_seconds: float) -> dict:
+        """BASELINE configs[4]: ONE 8192x8192x3 image, rows [H*g/G, H*(g+1)/G) resident on rank g; per step the ranks
+        exchange `radius` boundary rows with their neighbours (mi_blur_halo_exchange: ncclSend/ncclRecv pairs in one RCCL
+        group — split_image_blur.c:511-541 re-uploads the overlapping rows from the host instead) and blur their band.
+        Content is the LCG image the golden hashes were made from; the halo rows start as POISON, so a band that hashes
+        like the reference kernel's rows proves the exchange carried them.  Both step forms are timed over K2 steps each
+        (plain: exchange then band on one stream; overlapped: exchange on its own stream behind the interior rows, the 2R
+        edge rows after it) and the faster one is quoted."""
+        H = Wd = 8192
+        c, radius = 3, 1
+        b = pkg.band_of(H, radius, rank, world)
+        owned = b["row_end"] - b["row_begin"]
+        ht, hb = b["halo_top"], b["halo_bottom"]
+        rows = owned + ht + hb
+        pitch = Wd * c
+        band = torch.full((rows * pitch,), 0xA5, dtype=torch.uint8, device=dev)
+        out = torch.zeros(owned * pitch, dtype=torch.uint8, device=dev)
+        image = np.empty((H, Wd, c), np.uint8)                     # every rank generates the image and keeps its rows
+        L.mi_blur_fill_synthetic(image.ctypes.data, Wd, H, c, 0, 1, 1)
+        band[ht * pitch:(ht + owned) * pitch] = torch.from_numpy(image[b["row_begin"]:b["row_end"]].reshape(-1)).to(dev)
+        comm = C.c_void_p()
+        idbuf = torch.zeros(pkg.UNIQUE_ID_BYTES, dtype=torch.uint8)
+        # Rehearsal (tests, one-GPU box: MI_BLUR_BENCH_DEVICE set): RCCL refuses two ranks on one device, so the ranks
+        # run the whole control path — streams, events, barriers, reductions, the overlapped step, the parity check — with
+        # the exchange itself left out (the halo rows are uploaded instead).  Never taken on a real multi-GPU run.
+        fake_exchange = world > 1 and "MI_BLUR_BENCH_DEVICE" in os.environ
+        if fake_exchange:
+            if ht:
+                band[:ht * pitch] = torch.from_numpy(image[b["row_begin"] - ht:b["row_begin"]].reshape(-1)).to(dev)
+            if hb:
+                band[(ht + owned) * pitch:] = torch.from_numpy(image[b["row_end"]:b["row_end"] + hb].reshape(-1)).to(dev)
+        del image
+        if world > 1 and not fake_exchange:
+            if rank == 0:
+                raw = (C.c_uint8 * pkg.UNIQUE_ID_BYTES)()
+                pkg.check(L.mi_blur_comm_unique_id(raw), "comm_unique_id")
+                idbuf = torch.tensor(list(raw), dtype=torch.uint8)
+            idd = idbuf.to(dev) if backend == "nccl" else idbuf
+            dist.broadcast(idd, src=0)
+            idbuf = idd.cpu()
+        idarr = (C.c_uint8 * pkg.UNIQUE_ID_BYTES)(*idbuf.tolist())
+        comm_ranks, comm_transport = 1, 0
+        if not fake_exchange:
+            pkg.check(L.mi_blur_comm_init_rank(C.byref(comm), world, rank, idarr), "comm_init_rank")
+            nr, rk, tr = C.c_int(), C.c_int(), C.c_int()
+            pkg.check(L.mi_blur_comm_info(comm, C.byref(nr), C.byref(rk), C.byref(tr)), "comm_info")
+            if nr.value != world or rk.value != rank:
+                raise SystemExit(f"bench.py: communicator reports rank {rk.value} of {nr.value}, expected {rank} of {world}")
+            comm_ranks, comm_transport = nr.value, tr.value
+        main_stream = torch.cuda.current_stream()
+        stream = main_stream.cuda_stream
+
+        def exchange(on_stream):
+            if not fake_exchange:
+                pkg.check(L.mi_blur_halo_exchange(comm, band.data_ptr(), Wd, c, owned, radius, on_stream), "halo_exchange")
+
+        def blur_rows(y0, y1, dst_off):
+            pkg.check(L.mi_blur_enqueue_band(band.data_ptr(), out.data_ptr() + dst_off, Wd, rows, c, radius, y0, y1, stream), "enqueue_band")
+
+        def step():
+            exchange(stream)
+            blur_rows(ht, ht + owned, 0)
+
+        forms = {"plain": step}
+        if world > 1 and owned > 2 * radius:
+            xs = torch.cuda.Stream(device=dev)
+            ev_done, ev_halo = torch.cuda.Event(), torch.cuda.Event()
+
+            def step_overlapped():
+                xs.wait_event(ev_done)                                     # the previous step has read its halo rows
+                exchange(xs.cuda_stream)
+                ev_halo.record(xs)
+                blur_rows(ht + radius, ht + owned - radius, radius * pitch)    # interior: reads no halo row
+                main_stream.wait_event(ev_halo)
+                blur_rows(ht, ht + radius, 0)
+                blur_rows(ht + owned - radius, ht + owned, (owned - radius) * pitch)
+                ev_done.record(main_stream)
+
+            forms["overlapped"] = step_overlapped
+
+        # untimed ramp past the ~40 ms clock ramp that follows any idle gap.  A FIXED step count, the same on every rank:
+        # each step holds a send/recv pair, so ranks must not decide by their own clocks how many to run.
+        ramp_steps = int(ramp_seconds * 1e6 / 100.0)
+        for i in range(ramp_steps):
+            step()
+            if i % 64 == 63:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        want = golden.get("bands8192", {}).get("bands", {}).get(str(world))
+        want = want[rank] if want else None
+        timed, parity = {}, {"ok": True, "golden": "tests/golden bands8192 (reference kernel)", "band_fnv": {}}
+        for fname, fn in forms.items():
+            out.zero_()
+            if fname == "overlapped":
+                ev_done.record(main_stream)
+            for _ in range(W2):
+                fn()
+            barrier_sync()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            ev0.record()
+            for _ in range(K2):
+                fn()
+            ev1.record()
+            torch.cuda.synchronize()
+            loc = time.perf_counter() - t0        # this rank's K steps, from the common (barrier + sync) start to its own drain;
+            if world > 1:                         # the closing barrier + sync follow, then MAX over ranks: the job's time is
+                dist_barrier()                    # the slowest rank's, without the barrier's own latency added to every rank
+                torch.cuda.synchronize()
+            el = aggregate_max(loc, dist if world > 1 else None, dev if backend == "nccl" else None)
+            got = out.cpu().numpy()
+            fnv = f"{L.mi_blur_fnv1a64(got.ctypes.data, got.size):016x}"
+            parity["band_fnv"][fname] = fnv
+            if want is None:
+                parity["note"] = f"no golden band hashes for G={world}"
+            elif fnv != want:
+                parity["ok"] = False
+                parity["expected"] = want
+            timed[fname] = {"elapsed": el, "local": loc, "step_us": round(el / K2 * 1e6, 2), "stream_us": ev0.elapsed_time(ev1) * 1e3 / K2}
+        kernel_name = L.mi_blur_last_kernel().decode()
+        quoted = min(timed, key=lambda k: timed[k]["elapsed"])
+        bytes_per_launch = 2.0 * owned * pitch
+
+        # ---- per-step decomposition (outside the timed regions): exchange vs band kernel on this rank's stream
+        n_i = max(1, min(K2, 50))
+        ea = [torch.cuda.Event(enable_timing=True) for _ in range(3 * n_i)]
+        barrier_sync()
+        for i in range(n_i):
+            ea[3 * i].record()
+            exchange(stream)
+            ea[3 * i + 1].record()
+            blur_rows(ht, ht + owned, 0)
+            ea[3 * i + 2].record()
+        torch.cuda.synchronize()
+        x_us = sum(ea[3 * i].elapsed_time(ea[3 * i + 1]) for i in range(n_i)) * 1e3 / n_i
+        k_us = sum(ea[3 * i + 1].elapsed_time(ea[3 * i + 2]) for i in range(n_i)) * 1e3 / n_i
+        decomp = {"instrumented_steps": n_i, "halo_exchange_us": round(x_us, 2), "band_kernel_us": round(k_us, 2),
+                  "band_kernel_frac": frac_of(bytes_per_launch, k_us),
+                  "step_us_plain": timed["plain"]["step_us"]}
+        if "overlapped" in timed:
+            decomp["step_us_overlapped"] = timed["overlapped"]["step_us"]
+        if world > 1:      # the slowest rank's figures (rank 0 and the last rank have one neighbour only)
+            t = torch.tensor([decomp["halo_exchange_us"], decomp["band_kernel_us"]], dtype=torch.float64,
+                             device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            decomp["halo_exchange_us_max_over_ranks"], decomp["band_kernel_us_max_over_ranks"] = round(float(t[0]), 2), round(float(t[1]), 2)
+        if not fake_exchange:
+            L.mi_blur_comm_destroy(comm)
+        config = {"workload": f"one 8192x8192x3 image per step, 3x3, row-split over {world} GPU(s), RCCL halo exchange [BASELINE configs[4]]",
+                  "rows_per_gpu": owned, "halo_bytes_per_neighbour": radius * pitch, "ramp_steps": ramp_steps,
+                  "steps_per_form": K2, "step_forms_us": {k: v["step_us"] for k, v in timed.items()}, "quoted_form": quoted,
+                  "rccl_ranks": comm_ranks if comm_transport == 1 else 0,
+                  "halo_transport": {0: "none (one rank: both image edges clamp)", 1: "RCCL ncclSend/ncclRecv", 2: "peer copies"}[comm_transport],
+                  "step_decomposition": decomp}
+        if fake_exchange:
+            config["rehearsal"] = "halo exchange left out (two ranks share one device; halo rows uploaded); control path + parity only"
+            config["halo_transport"] = "none (rehearsal)"
+        parity["checked"] = f"rank band of {owned} rows, every step form"
+        q = timed[quoted]
+        del band, out
+        return {"value": K2 / q["elapsed"], "elapsed": q["elapsed"], "local": q["local"], "bytes_per_launch": bytes_per_launch,
+                "avg_launch_s": q["stream_us"] / 1e6, "kernel": kernel_name, "config": config, "parity": parity,
+                "timing_src": f"stream events around the {quoted} step (halo exchange + band kernel) on this rank's stream"}
+
     fused = args.workload == "a1" and args.dispatch == "fused" and args.batch < per_gpu_images
     if args.streams <= 0:
         args.streams = 4 if (args.workload == "a1" and not fused) else 1
     extra = {}
     other_line, other_key = None, None
     sustained = None
+    parity_line, completion, release_mode = None, None, None
     if args.workload in ("a1", "hd5"):
         if args.workload == "a1":
             h, w, c, radius, per_gpu, batch, pool = 256, 256, 3, 1, per_gpu_images, args.batch, per_gpu_images
@@ -421,7 +713,9 @@ def main() -> None:
         ctx = pkg.Context(local_rank, w, h, c, radius, max_batch=1, n_slots=args.streams, n_threads=host_threads)   # resident runs use no staging
         ctx.resident_alloc(pool)
         first, _ = shard_range(per_gpu * world, rank, world)       # image-level sharding: rank g owns [first, first + per_gpu)
-        ctx.resident_fill_synthetic(first)
+        # test hook (tests/test_cli.py): the last rank loads the WRONG shard, to show that the parity check fails the job
+        wrong = 1 if (os.environ.get("MI_BLUR_BENCH_FAULT") == "wrong_shard" and rank == world - 1) else 0
+        ctx.resident_fill_synthetic(first + wrong)
 
         def one_pass(timed):
             if fused:
@@ -473,6 +767,82 @@ def main() -> None:
                   "reference_published_on": "320x240x3, i7-12700 + UHD 770 (CPU+iGPU together)"}
         if fused:
             config["batches_counted_in_last_pass"] = ctx.resident_batches_done()
+
+        # ---- parity (after the clock has stopped): EVERY output image of this rank's shard is downloaded, hashed and compared
+        # with the unmodified reference kernel's hash of the same image of the stream (tests/golden/stream50k_image_fnv.npy).
+        # A rank that blurred the wrong shard, or wrongly, fails the job here.
+        parity_results = {}
+        if args.workload == "a1" and not args.no_parity:
+            pv = verify_resident_stream(pkg, L, ctx, first, per_gpu, h * w * c, golden, hash_threads)
+            pv["ok"] = pv["mismatches"] == 0
+            parity_results["a1_stream"] = pv
+        check_parity(parity_results)
+        if parity_results:
+            tot = torch.tensor([parity_results["a1_stream"]["checked"]], dtype=torch.int64,
+                               device=dev if (world > 1 and backend == "nccl") else "cpu")
+            if world > 1:
+                dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            parity_line = {"status": "ok" if int(tot.item()) > 0 else "unchecked",
+                           "a1_stream": {"images_checked_all_ranks": int(tot.item()), "mismatches": 0,
+                                         "rank0_first_image": first, "rank0_seconds": parity_results["a1_stream"].get("seconds"),
+                                         "against": "tests/golden/stream50k_image_fnv.npy: FNV-1a-64 of every output image of the "
+                                                    "50 000-image LCG stream through the unmodified reference kernel"}}
+            if "note" in parity_results["a1_stream"]:
+                parity_line["a1_stream"]["note"] = parity_results["a1_stream"]["note"]
+
+        if do_extra and fused:
+            # ---- the batch as the unit of COMPLETION, as the host sees it (per-batch clFinish, heterogeneous_blur.c:538-539):
+            # a poll loop on mi_blur_resident_batches_done during `passes` fused passes, each batch stamped with the host
+            # time at which a poll first reported it, measured from just before the dispatch call.
+            def batch_completion(passes=24):
+                nb = (per_gpu + batch - 1) // batch
+                seen_at = np.full((passes, nb), np.nan)
+                polls, poll_s, disp = 0, 0.0, []
+                for p in range(passes):
+                    ctx.sync()
+                    t_0 = time.perf_counter()
+                    ctx.resident_run_fused(per_gpu, batch)
+                    seen, deadline = 0, t_0 + 2.0
+                    while seen < nb:
+                        ta = time.perf_counter()
+                        nd = ctx.resident_batches_done()
+                        tb = time.perf_counter()
+                        polls += 1
+                        poll_s += tb - ta
+                        if nd > seen:
+                            seen_at[p, seen:nd] = tb - t_0
+                            seen = nd
+                        if tb > deadline:
+                            raise SystemExit(f"bench.py: fused pass: only {seen} of {nb} batches counted in after 2 s")
+                    ctx.sync()
+                    disp.append(time.perf_counter() - t_0)
+                med = np.median(seen_at, axis=0) * 1e6
+                return {"first": round(float(med[0]), 1), "p50": round(float(med[nb // 2]), 1), "last": round(float(med[-1]), 1),
+                        "batches": nb, "passes": passes, "polls_per_pass": round(polls / passes, 1), "poll_us": round(poll_s / polls * 1e6, 1),
+                        "pass_wall_us": round(float(np.median(disp)) * 1e6, 1),
+                        "how": "median over the passes of the host time (from just before the dispatch call) at which a "
+                               "mi_blur_resident_batches_done poll first reported batch k complete; the poll is a counter "
+                               "read-back on its own stream while the dispatch runs, so resolution = one poll"}
+
+            batch_completion(3)                                     # poll stream / code paths warm
+            completion = batch_completion()
+
+            # ---- the same pass with the ARCHITECTURAL completion protocol (release-ordered add at agent scope)
+            pkg.check(L.mi_blur_set_option(b"fused_release", 1), "set_option")
+            ctx.resident_run_fused(per_gpu, batch); ctx.sync(); ctx.reset_timing()
+            n_rel = 5
+            t_r0 = time.perf_counter()
+            for _ in range(n_rel):
+                ctx.resident_run_fused(per_gpu, batch, timed=True)
+            t_rel = ctx.sync()
+            wall_rel = time.perf_counter() - t_r0
+            rn, _rb = ctx.timed_coverage()
+            release_mode = {"dispatch_us": round(t_rel["kernel_ms"] * 1e3 / max(rn, 1), 1), "passes": n_rel,
+                            "img_s": round(n_rel * per_gpu / wall_rel, 0), "batches_counted_in": ctx.resident_batches_done(),
+                            "what": "mi_blur_set_option(\"fused_release\", 1): every block publishes with a release-ordered agent-scope "
+                                    "add (an L2 write-back per block) instead of write-through stores + relaxed add"}
+            pkg.check(L.mi_blur_set_option(b"fused_release", 0), "set_option")
+            ctx.resident_run_fused(per_gpu, batch); ctx.sync(); ctx.reset_timing()
 
         if do_extra:
             # ---- sustained: >= 1 s of back-to-back passes of the headline form (every 16th dispatch timestamped)
@@ -566,6 +936,17 @@ def main() -> None:
                                                    "frac": round(t1["bytes_alg"] / t1["launches"] / s / 1e9 / HBM_PEAK_GBS, 4),
                                                    "img_s": round(per_gpu / s, 0)}
         ctx.close()
+        if world > 1 and args.workload == "a1" and not args.no_extra:
+            # ---- the OTHER multi-GPU config on the same ranks: BASELINE configs[4], the 8192^2 row split with RCCL halo exchange
+            r2 = run_a2(200, 5, min(args.ramp_seconds, 0.25))
+            check_parity({"a2_8192_rowsplit": r2["parity"]})
+            extra["a2_8192_rowsplit"] = {"img_s": round(r2["value"], 1), "step_us": round(r2["elapsed"] / 200 * 1e6, 2), "scaling": "strong",
+                                         "kernel": r2["kernel"], "band_frac_of_hbm_peak": r2["config"]["step_decomposition"]["band_kernel_frac"],
+                                         **r2["config"]}
+            if parity_line is not None:
+                parity_line["a2_8192_rowsplit"] = r2["parity"]
+                if not r2["parity"].get("note"):
+                    parity_line["status"] = "ok"
         if do_extra:
             # BASELINE configs[2], configs[4] at N=1, and the PCIe-inclusive rate (host buffers in -> host buffers out)
             extra["hd1080_5x5"] = point_resident(1920, 1080, 3, 2, 64, 64, 64, 300,
@@ -577,136 +958,15 @@ def main() -> None:
                                                    "comparable to the reference's wall clock (heterogeneous_blur.c:415,603)"}
         base_shape = (h, w, c, radius)
     else:   # a2: one 8192x8192x3 image, row-split, RCCL halo exchange
-        H = Wd = 8192
-        c, radius = 3, 1
-        b = pkg.band_of(H, radius, rank, world)
-        owned = b["row_end"] - b["row_begin"]
-        ht = b["halo_top"]
-        rows = owned + ht + b["halo_bottom"]
-        pitch = Wd * c
-        band = torch.empty(rows * pitch, dtype=torch.uint8, device=dev)
-        out = torch.empty(owned * pitch, dtype=torch.uint8, device=dev)
-        # synthetic content: rank g's owned rows = LCG image seeded by rank (content is irrelevant to timing)
-        hostrows = np.empty((owned, Wd, c), np.uint8)
-        L.mi_blur_fill_synthetic(hostrows.ctypes.data, Wd, owned, c, rank, 1, 1)
-        band[ht * pitch:(ht + owned) * pitch] = torch.from_numpy(hostrows.reshape(-1)).to(dev)
-        comm = C.c_void_p()
-        idbuf = torch.zeros(pkg.UNIQUE_ID_BYTES, dtype=torch.uint8)
-        # Rehearsal (tests, one-GPU box: MI_BLUR_BENCH_DEVICE set): RCCL refuses two ranks on one device, so the ranks
-        # run the whole control path — streams, events, barriers, reductions, the overlapped step — with the exchange
-        # itself left out.  Never taken on a real multi-GPU run.
-        fake_exchange = world > 1 and "MI_BLUR_BENCH_DEVICE" in os.environ
-        if world > 1 and not fake_exchange:
-            if rank == 0:
-                raw = (C.c_uint8 * pkg.UNIQUE_ID_BYTES)()
-                pkg.check(L.mi_blur_comm_unique_id(raw), "comm_unique_id")
-                idbuf = torch.tensor(list(raw), dtype=torch.uint8)
-            idd = idbuf.to(dev) if backend == "nccl" else idbuf
-            dist.broadcast(idd, src=0)
-            idbuf = idd.cpu()
-        idarr = (C.c_uint8 * pkg.UNIQUE_ID_BYTES)(*idbuf.tolist())
-        if not fake_exchange:
-            pkg.check(L.mi_blur_comm_init_rank(C.byref(comm), world, rank, idarr), "comm_init_rank")
-        main_stream = torch.cuda.current_stream()
-        stream = main_stream.cuda_stream
-
-        def exchange(on_stream):
-            if not fake_exchange:
-                pkg.check(L.mi_blur_halo_exchange(comm, band.data_ptr(), Wd, c, owned, radius, on_stream), "halo_exchange")
-
-        def blur_rows(y0, y1, dst_off):
-            pkg.check(L.mi_blur_enqueue_band(band.data_ptr(), out.data_ptr() + dst_off, Wd, rows, c, radius, y0, y1, stream), "enqueue_band")
-
-        def step():
-            exchange(stream)
-            blur_rows(ht, ht + owned, 0)
-
-        # untimed ramp past the ~40 ms clock ramp that follows any idle gap.  A FIXED step count, the same on every rank:
-        # each step holds a send/recv pair, so ranks must not decide by their own clocks how many to run.
-        ramp_steps = int(args.ramp_seconds * 1e6 / 100.0)
-        for i in range(ramp_steps):
-            step()
-            if i % 64 == 63:
-                torch.cuda.synchronize()
-        for _ in range(W):
-            step()
-        barrier_sync()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record()
-        for _ in range(K):
-            step()
-        ev1.record()
-        torch.cuda.synchronize()
-        local = time.perf_counter() - t0          # this rank's K steps, from the common (barrier + sync) start to its own drain;
-        if world > 1:                             # the closing barrier + sync follow, then MAX over ranks: the job's time is
-            dist_barrier()                        # the slowest rank's, without the barrier's own latency added to every rank
-            torch.cuda.synchronize()
-        dominant_kernel = L.mi_blur_last_kernel().decode()
-        elapsed = aggregate_max(local, dist if world > 1 else None, dev if backend == "nccl" else None)
-        units = K
-        value = units / elapsed
-        scaling = "strong"
+        r2 = run_a2(K, W, args.ramp_seconds)
+        check_parity({"a2_8192_rowsplit": r2["parity"]})
+        value, elapsed, scaling, units = r2["value"], r2["elapsed"], "strong", K
         launches = timed_n = K
-        bytes_per_launch = 2.0 * owned * pitch
-        avg_launch_s = ev0.elapsed_time(ev1) / 1e3 / K          # exchange + kernel on this rank's stream
-        timing_src = "stream events around halo exchange + band kernel"
-
-        # ---- per-step decomposition (outside the timed region): exchange vs band kernel on this rank's stream, and the
-        # same step with the exchange on a stream of its own, hidden behind the interior rows (edge rows follow the halos)
-        n_i = max(1, min(K, 50))
-        ea = [torch.cuda.Event(enable_timing=True) for _ in range(3 * n_i)]
-        barrier_sync()
-        for i in range(n_i):
-            ea[3 * i].record()
-            exchange(stream)
-            ea[3 * i + 1].record()
-            blur_rows(ht, ht + owned, 0)
-            ea[3 * i + 2].record()
-        torch.cuda.synchronize()
-        x_us = sum(ea[3 * i].elapsed_time(ea[3 * i + 1]) for i in range(n_i)) * 1e3 / n_i
-        k_us = sum(ea[3 * i + 1].elapsed_time(ea[3 * i + 2]) for i in range(n_i)) * 1e3 / n_i
-        decomp = {"instrumented_steps": n_i, "halo_exchange_us": round(x_us, 2), "band_kernel_us": round(k_us, 2),
-                  "band_kernel_frac": frac_of(bytes_per_launch, k_us)}
-        if world > 1 and owned > 2 * radius:
-            xs = torch.cuda.Stream(device=dev)
-            ev_done, ev_halo = torch.cuda.Event(), torch.cuda.Event()
-
-            def step_overlapped():
-                xs.wait_event(ev_done)                                     # the previous step has read its halo rows
-                exchange(xs.cuda_stream)
-                ev_halo.record(xs)
-                blur_rows(ht + radius, ht + owned - radius, radius * pitch)    # interior: reads no halo row
-                main_stream.wait_event(ev_halo)
-                blur_rows(ht, ht + radius, 0)
-                blur_rows(ht + owned - radius, ht + owned, (owned - radius) * pitch)
-                ev_done.record(main_stream)
-
-            pair = []
-            for fn in (step, step_overlapped):
-                ev_done.record(main_stream)
-                fn()
-                barrier_sync()
-                t_p = time.perf_counter()
-                for _ in range(n_i):
-                    fn()
-                torch.cuda.synchronize()
-                pair.append(aggregate_max(time.perf_counter() - t_p, dist, dev if backend == "nccl" else None) * 1e6 / n_i)
-                if world > 1:
-                    dist_barrier()
-            decomp.update({"step_us_plain": round(pair[0], 2), "step_us_overlapped": round(pair[1], 2)})
-        if world > 1:      # the slowest rank's figures (rank 0 and the last rank have one neighbour only)
-            t = torch.tensor([decomp["halo_exchange_us"], decomp["band_kernel_us"]], dtype=torch.float64,
-                             device=dev if backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            decomp["halo_exchange_us_max_over_ranks"], decomp["band_kernel_us_max_over_ranks"] = round(float(t[0]), 2), round(float(t[1]), 2)
-        if not fake_exchange:
-            L.mi_blur_comm_destroy(comm)
-        config = {"workload": f"one 8192x8192x3 image per step, 3x3, row-split over {world} GPU(s), RCCL halo exchange [BASELINE configs[4]]",
-                  "rows_per_gpu": owned, "halo_bytes_per_neighbour": radius * pitch, "ramp_steps": ramp_steps, "step_decomposition": decomp}
-        if fake_exchange:
-            config["rehearsal"] = "halo exchange left out (two ranks share one device); control path only"
-        base_shape = (H, Wd, c, radius)
+        bytes_per_launch, avg_launch_s, timing_src = r2["bytes_per_launch"], r2["avg_launch_s"], r2["timing_src"]
+        dominant_kernel, config = r2["kernel"], r2["config"]
+        local = r2["local"]
+        parity_line = {"status": "unchecked" if r2["parity"].get("note") else "ok", "a2_8192_rowsplit": r2["parity"]}
+        base_shape = (8192, 8192, 3, 1)
 
     # which committed PMC run (profiles/traffic.json) matches this command's dominant kernel and launch shape
     traffic_key = args.workload
@@ -741,6 +1001,12 @@ def main() -> None:
             line["sustained"] = sustained
         if other_line:
             line[other_key] = other_line
+        if completion:
+            line["batch_completion_us"] = completion
+        if release_mode:
+            line["release_mode_us"] = release_mode
+        if parity_line:
+            line["parity"] = parity_line
         if extra:
             line["extra"] = extra
         print(json.dumps(line), flush=True)

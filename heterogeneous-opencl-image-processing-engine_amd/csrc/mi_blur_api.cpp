@@ -885,6 +885,8 @@ struct Rccl {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -914,6 +916,8 @@ Rccl &rccl()
         MI_SYM(CommInitRank, ncclCommInitRank);
         MI_SYM(CommInitAll, ncclCommInitAll);
         MI_SYM(CommDestroy, ncclCommDestroy);
+        MI_SYM(CommCount, ncclCommCount);
+        MI_SYM(CommUserRank, ncclCommUserRank);
         MI_SYM(Send, ncclSend);
         MI_SYM(Recv, ncclRecv);
         MI_SYM(GroupStart, ncclGroupStart);
@@ -1007,15 +1011,21 @@ extern "C" int mi_blur_comm_init_p2p(mi_blur_comm **comms, int n_devices, const 
     const int ndev = mi_blur_device_count();
     if (ndev <= 0) return MI_BLUR_ERR_NO_DEVICE;
     for (int i = 0; i < n_devices; i++) comms[i] = nullptr;
+    // any failure gives back every rank made so far (mi_blur_comm_destroy releases the events a rank already holds)
+    auto fail = [&](int rc) {
+        for (int j = 0; j < n_devices; j++) { mi_blur_comm_destroy(comms[j]); comms[j] = nullptr; }
+        return rc;
+    };
     for (int i = 0; i < n_devices; i++) {
         mi_blur_comm *c = new (std::nothrow) mi_blur_comm;
-        if (!c) return MI_BLUR_ERR_NOMEM;
+        if (!c) return fail(MI_BLUR_ERR_NOMEM);
         c->n_ranks = n_devices; c->rank = i; c->device = devices ? devices[i] : i; c->p2p = true;
         comms[i] = c;
-        if (c->device < 0 || c->device >= ndev) return MI_BLUR_ERR_NO_DEVICE;
-        HIP_TRY(hipSetDevice(c->device));
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_prev, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_push, hipEventDisableTiming));
+        if (c->device < 0 || c->device >= ndev) return fail(MI_BLUR_ERR_NO_DEVICE);
+        hipError_t e = hipSetDevice(c->device);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_prev, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_push, hipEventDisableTiming);
+        if (e != hipSuccess) { (void)hipGetLastError(); return fail(MI_BLUR_ERR_HIP_BASE - (int)e); }
     }
     for (int i = 0; i + 1 < n_devices; i++) {     // neighbours on different devices: enable direct access both ways (best effort)
         const int a = comms[i]->device, b = comms[i + 1]->device;
@@ -1025,6 +1035,25 @@ extern "C" int mi_blur_comm_init_p2p(mi_blur_comm **comms, int n_devices, const 
         if (hipDeviceCanAccessPeer(&can, b, a) == hipSuccess && can) { (void)hipSetDevice(b); (void)hipDeviceEnablePeerAccess(a, 0); }
         (void)hipGetLastError();
     }
+    return MI_BLUR_OK;
+}
+
+// What a communicator IS, as the transport itself reports it: a bench line that says "RCCL carried the halos over N
+// ranks" quotes ncclCommCount / ncclCommUserRank, not the number it asked for.
+extern "C" int mi_blur_comm_info(mi_blur_comm *c, int *n_ranks, int *rank, int *transport)
+{
+    if (!c) return MI_BLUR_ERR_INVALID;
+    int n = c->n_ranks, r = c->rank, t = c->p2p ? 2 : (c->comm ? 1 : 0);
+    if (c->comm) {
+        Rccl &rc = rccl();
+        if (!rc.ok || !rc.CommCount || !rc.CommUserRank) return MI_BLUR_ERR_UNSUPPORTED;
+        int e = nccl_status(rc.CommCount(c->comm, &n));
+        if (!e) e = nccl_status(rc.CommUserRank(c->comm, &r));
+        if (e) return e;
+    }
+    if (n_ranks) *n_ranks = n;
+    if (rank) *rank = r;
+    if (transport) *transport = t;
     return MI_BLUR_OK;
 }
 

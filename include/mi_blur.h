@@ -326,6 +326,11 @@ int mi_blur_comm_init_all(mi_blur_comm **comms, int n_devices, const int *device
  * only one that accepts several ranks on one device).  Use with mi_blur_halo_exchange_all. */
 int mi_blur_comm_init_p2p(mi_blur_comm **comms, int n_devices, const int *devices);
 void mi_blur_comm_destroy(mi_blur_comm *comm);
+/* What the communicator is, as its transport reports it: *n_ranks / *rank from ncclCommCount / ncclCommUserRank for an
+ * RCCL communicator (the numbers a report should quote for "RCCL carried the halos over N ranks"), the construction
+ * arguments otherwise; *transport 0 = none (a single rank: both image edges clamp), 1 = RCCL, 2 = peer copies.
+ * Any out pointer may be NULL. */
+int mi_blur_comm_info(mi_blur_comm *comm, int *n_ranks, int *rank, int *transport);
 
 /* d_band: this rank's shard laid out as [halo_top rows][owned rows][halo_bottom rows]
  * (halo_* from mi_blur_band_of; absent halos have zero rows).  Sends the first/last

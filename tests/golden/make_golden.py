@@ -20,9 +20,18 @@ Writes
                      through the reference kernel: FNV-1a-64 of the 983 040 000 output bytes laid end to end, and the
                      FNV of the 5000 per-image output hashes (little-endian u64 each) — what the GPU tests assert for
                      the per-batch-launch and the fused forms of the resident stream.
+  "bands8192" section  BASELINE configs[4] (one 8192x8192x3 image row-split over G GPUs): FNV-1a-64 of the reference
+                     kernel's output rows [H*g/G, H*(g+1)/G) for G in {1, 2, 3, 4, 6, 8} — what rank g of `bench.py --gpus G`
+                     must hold after halo exchange + band blur (split_image_blur.c:511-541 semantics, K-way).
+  stream50k_image_fnv.npy + "stream50k" section
+                     BASELINE configs[3] (50 000 x 256x256x3, image i = LCG seeded 0x9E3779B9 ^ i) through the reference
+                     kernel: the FNV-1a-64 of EVERY output image (little-endian u64 x 50 000 = 400 KB), so that any rank of
+                     any N can check every image of its shard; the JSON section holds the digest of that file's payload
+                     and of each rank's slice for N in {1, 2, 4, 8}.
 Fixtures are data (inputs/expected outputs); no reference source is stored.
 
     python tests/golden/make_golden.py --stream-only     # recompute only the "stream" section (keeps the rest)
+    python tests/golden/make_golden.py --multi-gpu-only  # recompute only "bands8192" / "stream50k" (keeps the rest)
 """
 import json
 import os
@@ -67,8 +76,58 @@ def stream_section(n: int = 5000, h: int = 256, w: int = 256, c: int = 3, thread
             "image_fnv": {str(i): hx(int(per_image[i])) for i in (0, 34, 35, 2499, 4969, 4999)}}
 
 
+def bands8192_section(h: int = 8192, w: int = 8192, c: int = 3) -> dict:
+    """configs[4]: per-band hashes of the reference kernel's output of the one LCG image (seed index 0)."""
+    img = O.lcg_image(h, w, c)
+    out = O.ref_blur(img)
+    sec = {"h": h, "w": w, "c": c, "radius": 1, "in_fnv": hx(O.fnv1a64(img)), "out_fnv": hx(O.fnv1a64(out)), "bands": {}}
+    for G in (1, 2, 3, 4, 6, 8):
+        sec["bands"][str(G)] = [hx(O.fnv1a64(out[h * g // G:h * (g + 1) // G])) for g in range(G)]
+    return sec
+
+
+def stream50k_section(n: int = 50000, h: int = 256, w: int = 256, c: int = 3, threads: int = 8, chunk: int = 1000) -> dict:
+    """configs[3]: every image of the 50 000-image stream through the UNMODIFIED reference kernel; per-image FNVs."""
+    import threading
+    rlib = O.ref()
+    isz = h * w * c
+    per_image = np.empty(n, dtype="<u8")
+    for first in range(0, n, chunk):
+        m = min(chunk, n - first)
+        src = O.lcg_stream(m, h, w, c, first_index=first)
+        out = np.empty_like(src)
+
+        def work(b, e):
+            for i in range(b, e):
+                rlib.ref_gaussian_blur(src.ctypes.data + i * isz, out.ctypes.data + i * isz, w, h, c)
+                per_image[first + i] = O.fnv1a64(out[i])
+
+        th = [threading.Thread(target=work, args=(m * t // threads, m * (t + 1) // threads)) for t in range(threads)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert np.array_equal(out[m - 1], O.blur(src[m - 1], 1)), first      # the restatement agrees on a sample
+        print(f"stream50k: {first + m} / {n}", flush=True)
+    np.save(os.path.join(HERE, "stream50k_image_fnv.npy"), per_image)
+    sec = {"n": n, "h": h, "w": w, "c": c, "radius": 1, "file": "stream50k_image_fnv.npy",
+           "per_image_fnv_digest": hx(O.fnv1a64(per_image.view(np.uint8))), "rank_digest": {}}
+    for G in (1, 2, 4, 8):
+        sec["rank_digest"][str(G)] = [hx(O.fnv1a64(per_image[n * g // G:n * (g + 1) // G].view(np.uint8))) for g in range(G)]
+    return sec
+
+
 def main() -> None:
     O.build(ref=True)
+    if "--multi-gpu-only" in sys.argv:
+        path = os.path.join(HERE, "blur_golden.json")
+        gold = json.load(open(path))
+        gold["bands8192"] = bands8192_section()
+        print("bands8192:", gold["bands8192"]["out_fnv"], flush=True)
+        gold["stream50k"] = stream50k_section()
+        with open(path, "w") as f:
+            json.dump(gold, f, indent=1)
+        return
     if "--stream-only" in sys.argv:
         path = os.path.join(HERE, "blur_golden.json")
         gold = json.load(open(path))
@@ -122,6 +181,8 @@ def main() -> None:
                                     "first": out.reshape(-1)[:8].tolist()})
 
     gold["stream"] = stream_section()
+    gold["bands8192"] = bands8192_section()
+    gold["stream50k"] = stream50k_section()
 
     with open(os.path.join(HERE, "blur_golden.json"), "w") as f:
         json.dump(gold, f, indent=1)

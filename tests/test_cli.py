@@ -231,13 +231,28 @@ def test_bench_spawns_its_own_ranks(pkg):
     r = subprocess.run(cmd + ["--images", "700"], cwd=pkg.ROOT, env=dict(env, MI_BLUR_BENCH_BACKEND="gloo", MI_BLUR_BENCH_DEVICE="0"),
                        capture_output=True, text=True, timeout=600)
     d = _bench_line(r)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d and "extra" not in d
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d
     assert d["config"]["images_per_gpu_per_step"] == 700 and d["config"]["images_per_step"] == 1400 and d["roofline"]["bound"] == "hbm"
+    # ONE invocation carries BOTH multi-GPU configs and has checked the pixels of both against the reference kernel's hashes:
+    # every image of both shards (configs[3]) and each rank's band of the 8192^2 output in both step forms (configs[4])
+    assert d["parity"]["status"] == "ok" and d["parity"]["a1_stream"] == dict(d["parity"]["a1_stream"], images_checked_all_ranks=1400, mismatches=0)
+    a2 = d["extra"]["a2_8192_rowsplit"]
+    assert "configs[4]" in a2["workload"] and a2["rows_per_gpu"] == 4096 and a2["scaling"] == "strong" and a2["img_s"] > 0
+    assert set(a2["step_forms_us"]) == {"plain", "overlapped"} and a2["quoted_form"] in a2["step_forms_us"] and a2["steps_per_form"] == 200
+    assert a2["rccl_ranks"] == 0 and "rehearsal" in a2                    # exchange leg left out on a one-GPU box, and the line says so
+    pa = d["parity"]["a2_8192_rowsplit"]
+    assert pa["ok"] and set(pa["band_fnv"]) == {"plain", "overlapped"} and pa["band_fnv"]["plain"] == pa["band_fnv"]["overlapped"] == "0d04249de0140100"
+    # the check bites: a rank that holds the wrong shard fails the whole job, and no line is printed
+    r = subprocess.run(cmd + ["--images", "700", "--no-extra"], cwd=pkg.ROOT, capture_output=True, text=True, timeout=600,
+                       env=dict(env, MI_BLUR_BENCH_BACKEND="gloo", MI_BLUR_BENCH_DEVICE="0", MI_BLUR_BENCH_FAULT="wrong_shard"))
+    assert r.returncode != 0 and "PARITY FAILURE" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")], r.stdout + r.stderr
     # default share at N=2 is 50000 // 2 per GPU (configs[3]); two ranks on one device hold 2 x 9.8 GB
     r = subprocess.run(cmd, cwd=pkg.ROOT, env=dict(env, MI_BLUR_BENCH_BACKEND="gloo", MI_BLUR_BENCH_DEVICE="0"),
                        capture_output=True, text=True, timeout=900)
     d = _bench_line(r)
     assert d["n_gpus"] == 2 and d["config"]["images_per_gpu_per_step"] == 25000 and "configs[3]" in d["config"]["workload"]
+    assert d["parity"]["status"] == "ok" and d["parity"]["a1_stream"]["images_checked_all_ranks"] == 50000
+    assert d["extra"]["a2_8192_rowsplit"]["img_s"] > 0 and d["parity"]["a2_8192_rowsplit"]["ok"]
     if torch.cuda.device_count() < 2:
         r = subprocess.run(cmd, cwd=pkg.ROOT, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode != 0 and "only 1 HIP device" in r.stderr and not r.stdout.strip(), r.stdout + r.stderr
@@ -275,6 +290,9 @@ def test_bench_a2_two_rank_rehearsal(pkg):
     d = _bench_line(r)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["rows_per_gpu"] == 4096 and d["config"]["halo_bytes_per_neighbour"] == 8192 * 3 and "rehearsal" in d["config"]
+    assert d["config"]["steps_per_form"] == 10 and d["config"]["quoted_form"] in ("plain", "overlapped") and d["config"]["rccl_ranks"] == 0
+    assert abs(d["ms_per_step"] * 1e3 - min(d["config"]["step_forms_us"].values())) < 0.06      # value quotes the faster form (ms rounded to 1e-4)
+    assert d["parity"]["status"] == "ok" and d["parity"]["a2_8192_rowsplit"]["band_fnv"]["plain"] == "0d04249de0140100"
     dec = d["config"]["step_decomposition"]
     assert dec["band_kernel_us"] > 0 and dec["halo_exchange_us"] >= 0 and dec["step_us_plain"] > 0 and dec["step_us_overlapped"] > 0
     assert 0 < dec["band_kernel_frac"] <= 1 and dec["band_kernel_us_max_over_ranks"] >= dec["band_kernel_us"] - 1e-6
@@ -292,7 +310,15 @@ def test_bench_default_line_carries_every_single_gpu_config(pkg):
     d = _bench_line(r)
     assert d["n_gpus"] == 1 and d["dtype"] == "u8" and "configs[1]" in d["config"]["workload"] and d["vs_baseline"] is None
     assert 0 < d["roofline"]["frac"] <= 1 and d["roofline"]["kernel"] == "blur_fused_kernel" and d["roofline"]["launches_timed"] == 20
-    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["kind"] == "port"
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port"
+    assert cb["one_thread"]["cores"] == 1 and 0 < cb["one_thread"]["value"] <= cb["value"] * 1.05
+    assert cb["product_cpu_device"]["value"] > 0 and cb["product_cpu_device"]["one_thread"]["cores"] == 1
+    assert d["parity"]["status"] == "ok" and d["parity"]["a1_stream"]["images_checked_all_ranks"] == 5000
+    bc = d["batch_completion_us"]
+    assert bc["batches"] == 143 and 0 < bc["first"] <= bc["p50"] <= bc["last"] and bc["passes"] >= 20
+    assert bc["first"] < 0.6 * bc["last"], bc          # batches are visible to the host long before the dispatch ends
+    assert d["release_mode_us"]["dispatch_us"] > d["roofline"]["avg_launch_us"] and d["release_mode_us"]["batches_counted_in"] == 143
     assert d["sustained"]["seconds"] >= 1.0 and d["sustained_img_s"] > 0
     ex = d["extra"]
     assert set(ex) >= {"hd1080_5x5", "a2_8192_1gpu", "e2e_pcie_inclusive", "one_launch_5000_images"}

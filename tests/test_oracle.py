@@ -52,6 +52,31 @@ def test_golden_k3_large(O, golden):
     assert f"{O.fnv1a64(out):016x}" == e["out_fnv"]
 
 
+def test_golden_multi_gpu_sections(O, golden):
+    """The fixtures bench.py's multi-GPU parity check reads (reference-kernel outputs, tests/golden/make_golden.py
+    --multi-gpu-only): per-band hashes of the 8192^2 output for G GPUs, and the hash of EVERY output image of the
+    50 000-image stream.  The oracle reproduces the bands and a sample of the images; the digests tie the file down."""
+    sec = golden["bands8192"]
+    assert sec["out_fnv"] == [x for x in golden["k3"] if x["h"] == 8192][0]["out_fnv"] and sec["bands"]["1"] == [sec["out_fnv"]]
+    out = O.blur(O.lcg_image(8192, 8192, 3), 1)
+    for G, want in sec["bands"].items():
+        G = int(G)
+        assert [f"{O.fnv1a64(out[8192 * g // G:8192 * (g + 1) // G]):016x}" for g in range(G)] == want, G
+    del out
+    st = golden["stream50k"]
+    per = np.load(os.path.join(os.path.dirname(__file__), "golden", st["file"]))
+    assert per.dtype == np.dtype("<u8") and per.shape == (50000,)
+    assert f"{O.fnv1a64(per.view(np.uint8)):016x}" == st["per_image_fnv_digest"]
+    for G, want in st["rank_digest"].items():
+        G = int(G)
+        assert [f"{O.fnv1a64(per[50000 * g // G:50000 * (g + 1) // G].view(np.uint8)):016x}" for g in range(G)] == want
+    # the first 5000 are the headline stream of the "stream" section
+    assert f"{O.fnv1a64(per[:5000].view(np.uint8)):016x}" == golden["stream"]["per_image_fnv_digest"]
+    for i in (0, 4999, 5000, 6249, 6250, 12500, 24999, 25000, 43750, 49999):
+        img = O.lcg_stream(1, 256, 256, 3, first_index=i)[0]
+        assert O.fnv1a64(O.blur(img, 1)) == int(per[i]), i
+
+
 def test_golden_literals(O, golden):
     for lit in golden["literals"]:
         img = np.array(lit["in"], np.uint8).reshape(lit["h"], lit["w"], lit["c"])

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Developer probe: a short end-to-end run (pinned host buffers in -> out, zero-copy submits) meant to be traced:
+
+    rocprofv3 --hip-trace --kernel-trace --output-format csv -d gpurun_out/e2e_trace -- python3 tools/e2e_timeline.py [batch] [slots] [submits]
+
+Warm-up submits first (so code-object load and clock ramp stay out of the traced window), then `submits` timed ones with a
+host timestamp around every mi_blur_submit call.  Prints the host-side split; tools/e2e_timeline_report.py folds the
+rocprofv3 CSVs into profiles/r03_e2e_timeline.md."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+
+def main():
+    import torch  # noqa: F401  (loads the HIP runtime first, see hoipe_amd.lib)
+    nb = int(sys.argv[1]) if len(sys.argv) > 1 else 35
+    ns = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    n_sub = int(sys.argv[3]) if len(sys.argv) > 3 else 60
+    pkg = entry.load_package()
+    L = pkg.lib()
+    w, h, c, r = 256, 256, 3, 1
+    nbytes = nb * h * w * c
+    bufs = [(L.mi_blur_host_alloc(nbytes), L.mi_blur_host_alloc(nbytes)) for _ in range(ns)]
+    for (pi, _po) in bufs:
+        L.mi_blur_fill_synthetic(pi, w, h, c, 0, nb, 4)
+    ctx = pkg.Context(0, w, h, c, r, max_batch=nb, n_slots=ns)
+    t_end = time.perf_counter() + 0.3
+    i = 0
+    while time.perf_counter() < t_end:                  # warm: code objects, clocks
+        ctx.submit(bufs[i % ns][0], bufs[i % ns][1], nb)
+        i += 1
+    ctx.sync()
+    ctx.reset_timing()
+    calls = []
+    t0 = time.perf_counter()
+    for i in range(n_sub):
+        a = time.perf_counter()
+        ctx.submit(bufs[i % ns][0], bufs[i % ns][1], nb)
+        calls.append(time.perf_counter() - a)
+    tm = ctx.sync()
+    dt = time.perf_counter() - t0
+    calls_us = sorted(x * 1e6 for x in calls)
+    print(f"batch {nb} slots {ns}: {n_sub} submits in {dt * 1e3:.2f} ms = {dt / n_sub * 1e6:.1f} us per submit, "
+          f"{n_sub * nb / dt:.0f} img/s, {n_sub * nbytes / dt / 1e9:.1f} GB/s each way; "
+          f"mi_blur_submit call: median {calls_us[len(calls_us) // 2]:.1f} us, min {calls_us[0]:.1f}, max {calls_us[-1]:.1f}; "
+          f"kernel bucket {tm['kernel_ms']:.2f} ms (union of dispatch intervals) = {tm['kernel_ms'] / (dt * 1e3) * 100:.0f} % of the wall clock",
+          flush=True)
+    for (pi, po) in bufs:
+        L.mi_blur_host_free(pi)
+        L.mi_blur_host_free(po)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
