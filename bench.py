@@ -396,6 +396,10 @@ def main() -> None:
 
     pkg = entry.load_package()
     L = pkg.lib()
+    # this rank's host work (stream generation, hashing, the a2 image, launch threads) stays on its GPU's socket; threads
+    # started from here on inherit the mask.  0 = nothing changed (MI_BLUR_NO_AFFINITY, or sysfs does not expose the topology)
+    host_cpus_bound = L.mi_blur_bind_thread_to_device(local_rank)
+    host_cpulist, host_node = pkg.device_cpulist(local_rank)
     K, W = args.steps, args.warmup
     per_gpu_images = args.images if args.images > 0 else default_images(world)
     do_extra = world == 1 and args.workload == "a1" and not args.no_extra
@@ -986,6 +990,8 @@ def main() -> None:
         roofline["whole_step_gbs_per_gpu"] = round(step_bytes * K / local / 1e9, 1)
         roofline["whole_step_frac"] = round(step_bytes * K / local / 1e9 / HBM_PEAK_GBS, 4)
 
+    config["host_placement"] = ({"cpus": host_cpulist, "numa_node": host_node, "cpus_allowed_there": host_cpus_bound} if host_cpus_bound
+                                else "not pinned (MI_BLUR_NO_AFFINITY or topology not exposed)")
     line = {"metric": "images_per_sec", "value": round(value, 1), "unit": "img/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",

@@ -131,9 +131,13 @@ def lib() -> C.CDLL:
         "mi_blur_destroy": (None, [vp]),
         "mi_blur_host_alloc": (vp, [C.c_size_t]),
         "mi_blur_host_free": (None, [vp]),
+        "mi_blur_device_cpulist": (i, [i, C.c_char_p, C.c_size_t, C.POINTER(i)]),
+        "mi_blur_bind_thread_to_device": (i, [i]),
+        "mi_blur_host_alloc_on": (vp, [i, C.c_size_t]),
         "mi_blur_submit": (i, [vp, u8p, u8p, i]),
         "mi_blur_submit_band": (i, [vp, u8p, u8p, i, i, i]),
         "mi_blur_submit_bands": (i, [vp, u8p, u8p, i, C.c_size_t, i, i, i]),
+        "mi_blur_submit_planar": (i, [vp, u8p, u8p, i, i]),
         "mi_blur_wait_oldest": (i, [vp]),
         "mi_blur_sync": (i, [vp, C.POINTER(Timing)]),
         "mi_blur_reset_timing": (None, [vp]),
@@ -192,6 +196,14 @@ def shard_range(n_units: int, g: int, G: int) -> tuple[int, int]:
     return b.value, e.value
 
 
+def device_cpulist(device: int) -> tuple[str, int]:
+    """(local CPU list as sysfs spells it, NUMA node) of a GPU; ("", -1) when the topology is not exposed."""
+    buf = C.create_string_buffer(512)
+    node = C.c_int(-1)
+    rc = lib().mi_blur_device_cpulist(device, buf, len(buf), C.byref(node))
+    return (buf.value.decode() if rc == OK else "", node.value)
+
+
 def a2_split(height: int, gpu_ratio: float, halo: int = 1) -> dict:
     g = A2Geometry()
     lib().mi_blur_a2_split(height, gpu_ratio, halo, C.byref(g))
@@ -238,6 +250,12 @@ class Context:
     def submit_band(self, host_in, host_out, band_rows: int, halo_top: int, halo_bottom: int) -> None:
         check(lib().mi_blur_submit_band(self.h, host_in, host_out, band_rows, halo_top, halo_bottom),
               "mi_blur_submit_band")
+
+    def submit_planar(self, host_planar_in, host_out, n_images: int, planar_out: bool = False) -> None:
+        check(lib().mi_blur_submit_planar(self.h, host_planar_in, host_out, n_images, 1 if planar_out else 0), "mi_blur_submit_planar")
+
+    def wait_oldest(self) -> None:
+        check(lib().mi_blur_wait_oldest(self.h), "mi_blur_wait_oldest")
 
     def sync(self) -> dict:
         t = Timing()

@@ -3,6 +3,7 @@
 //   heterogeneous_blur {cpu|gpu|both} [gpu_ratio] [batch]  [--image F | --synthetic | --size WxH] [--channels C]
 //                      [--ksize 3|5] [--images N] [--gpus G] [--slots S] [--threads T] [--resident [--fused]]
 //                      [--verbose] [--csv FILE] [--save FILE]
+//                      [--frames DIR|PATTERN|FILE [--save-dir DIR] [--planar-out]]   (cpu | gpu)
 //
 // Same positional command line, banner and report sections as the reference host
 // (heterogeneous_blur.c:41-100 CLI, :406-601 batch loop, :609-724 report).  What changed:
@@ -15,10 +16,16 @@
 //   * batch buffers are pinned and rotate through `slots` sets, so batch n+1 is built and uploaded
 //     while batch n computes; the reference's per-batch malloc/free (:431-432,596-597) is hoisted,
 //     its per-batch stream construction (memcpy of the source image into every slot, :440-442)
-//     stays inside the timed region as in the reference.
+//     stays inside the timed region as in the reference;
+//   * `gpu` mode runs ONE FEEDER THREAD PER GPU (the reference's one host thread drives both of its devices,
+//     :482-539): feeder g builds GPU g's contiguous share of every batch in its own pinned buffers and submits it;
+//     the feeder, its batch-building helpers and its buffers keep to the CPUs / memory of that GPU's socket
+//     (mi_blur_bind_thread_to_device, mi_blur_host_alloc_on; MI_BLUR_NO_AFFINITY=1 turns that off).
 #include "host_common.h"
 
 using namespace host;
+
+static int run_frames(const Options &opt, int mode, int BATCH_SIZE, const std::vector<std::string> &files);
 
 struct Dev {
     mi_blur_ctx *ctx = nullptr;
@@ -38,6 +45,14 @@ int main(int argc, char **argv)
 
     Options opt;
     const int npos = parse_flags(argc, argv, opt);
+    // --frames: the stream is a set of DISTINCT frame files (not one image copied NUM_IMAGES times, :439-442)
+    std::vector<std::string> frame_files;
+    if (!opt.frames.empty()) {
+        frame_files = list_frames(opt.frames);
+        if (frame_files.empty()) { printf("Error: no frame files found for --frames %s\n", opt.frames.c_str()); return -1; }
+        if (opt.images_given && opt.images < (int)frame_files.size()) frame_files.resize(opt.images);
+        opt.images = (int)frame_files.size();
+    }
     const int NUM_IMAGES = opt.images;
 
     if (npos > 1) {
@@ -72,7 +87,8 @@ int main(int argc, char **argv)
     if (mode == 0 && opt.auto_ratio) printf("GPU ratio: auto (first batch split 50/50, then the measured optimum)\n");
     else if (mode == 0) printf("GPU ratio: %.1f%% GPU, %.1f%% CPU\n", gpu_ratio * 100, (1 - gpu_ratio) * 100);
     printf("========== HETEROGENEOUS CONFIGURATION ==========\n");
-    printf("Input file: %s\n", opt.synthetic ? "(synthetic)" : input_filename);
+    if (!frame_files.empty()) printf("Input frames: %s (%zu files, %s ... %s)\n", opt.frames.c_str(), frame_files.size(), frame_files.front().c_str(), frame_files.back().c_str());
+    else printf("Input file: %s\n", opt.synthetic ? "(synthetic)" : input_filename);
     printf("Number of images in stream: %d\n", NUM_IMAGES);
     printf("Batch size: %d images\n", BATCH_SIZE);
     printf("Number of batches: %d\n", NUM_BATCHES);
@@ -80,6 +96,12 @@ int main(int argc, char **argv)
     printf("Execution mode : %d\n", mode);
     printf("Blur kernel: %dx%d\n", opt.ksize, opt.ksize);
     printf("================================================\n\n");
+
+    if (!frame_files.empty()) {
+        if (mode == 0) { printf("Error: --frames runs on one device kind: use mode cpu or gpu\n"); return -1; }
+        if (opt.resident) { printf("Error: --frames and --resident exclude each other\n"); return -1; }
+        return run_frames(opt, mode, BATCH_SIZE, frame_files);
+    }
 
     // ---------------- load original image (heterogeneous_blur.c:104-137)
     Image img = load_image(input_filename, opt.syn_w, opt.syn_h, opt.syn_c, opt.synthetic);
@@ -124,12 +146,25 @@ int main(int argc, char **argv)
         printf("GPU device: %s\n", gpus[g].name.c_str());
         gpus[g].submitted.assign(NUM_BATCHES, 0);
     }
+    // gpu mode from host buffers: one feeder thread per GPU, each with its own buffers, placed on the GPU's socket
+    const bool per_gpu_feeders = mode == 2 && !opt.resident;
+    for (int g = 0; g < G; g++) report_placement(g, hip_ordinal(g), /*bind the calling thread*/ !per_gpu_feeders && g == 0);
     printf("\nKernel objects created (code objects are embedded in libmi_blur.so; nothing is read from the CWD)\n\n");
 
     // ---------------- buffers (heterogeneous_blur.c:330-357,431-437): pinned, `nslots` rotating sets
     printf("Allocating device buffers...\n");
     std::vector<uint8_t *> batch_input(nslots, nullptr), batch_output(nslots, nullptr);
-    if (!opt.resident) {
+    std::vector<std::vector<uint8_t *>> gin(G), gout(G);               // per_gpu_feeders: GPU g's own rotating buffer sets
+    if (per_gpu_feeders) {
+        for (int g = 0; g < G; g++) {
+            const size_t share = (size_t)(BATCH_SIZE + G - 1) / G;     // the largest contiguous share of a batch (mi_blur_shard_range)
+            for (int s = 0; s < nslots; s++) {
+                gin[g].push_back((uint8_t *)mi_blur_host_alloc_on(hip_ordinal(g), share * image_size));
+                gout[g].push_back((uint8_t *)mi_blur_host_alloc_on(hip_ordinal(g), share * image_size));
+                if (!gin[g].back() || !gout[g].back()) { printf("Error: Failed to allocate batch memory\n"); return -1; }
+            }
+        }
+    } else if (!opt.resident) {
         for (int s = 0; s < nslots; s++) {
             batch_input[s] = (uint8_t *)mi_blur_host_alloc((size_t)BATCH_SIZE * image_size);
             batch_output[s] = (uint8_t *)mi_blur_host_alloc((size_t)BATCH_SIZE * image_size);
@@ -155,7 +190,7 @@ int main(int argc, char **argv)
 
     // Warm-up outside the clock: first-use costs (code-object load, worker threads) would otherwise land in the first
     // batch — harmless for the totals, fatal for "auto", which calibrates on that batch.
-    if (!opt.resident) {
+    if (!opt.resident && !per_gpu_feeders) {
         const int nw = std::min(BATCH_SIZE, 4);
         for (int i = 0; i < nw; i++) memcpy(batch_input[0] + (size_t)i * image_size, original_image, image_size);
         if (cpu.ctx) { mi_check(mi_blur_submit(cpu.ctx, batch_input[0], batch_output[0], nw), "CPU warm-up failed"); mi_check(mi_blur_sync(cpu.ctx, nullptr), "CPU sync failed"); mi_blur_reset_timing(cpu.ctx); }
@@ -181,12 +216,69 @@ int main(int argc, char **argv)
     printf("Starting batch processing of %d images in %d batches...\n\n", NUM_IMAGES, NUM_BATCHES);
     int total_images_cpu = 0, total_images_gpu = 0;
     std::vector<uint8_t> first_output;
-    Replicator replicate(opt.host_threads);
+    Replicator replicate(per_gpu_feeders ? 1 : opt.host_threads, (mode != 1 && G > 0) ? hip_ordinal(0) : -1);
     double last_harvest_ms = 0;
     int rebalances = 0;
-    const double time_start_total = get_time_ms();
+    double time_start_total = get_time_ms();
 
-    if (opt.resident) {
+    if (per_gpu_feeders) {
+        // One feeder per GPU.  Feeder g owns images [b, e) = mi_blur_shard_range(batch_count, g, G) of EVERY batch (:496),
+        // builds them in its own pinned buffers (the memcpy of :439-442, inside the timed region) and submits them; the
+        // GPUs never wait for one another.  All feeders warm up (code-object load, worker threads, clocks), meet at a
+        // gate, and the clock starts when the gate opens.
+        std::atomic<int> at_gate{0};
+        std::atomic<bool> go{false};
+        std::vector<int> feed_rc(G, MI_BLUR_OK);
+        std::vector<std::thread> feeders;
+        for (int g = 0; g < G; g++) {
+            feeders.emplace_back([&, g]() {
+                const int ord = hip_ordinal(g);
+                mi_blur_bind_thread_to_device(ord);
+                Replicator rep(opt.host_threads, ord);
+                mi_blur_ctx *ctx = gpus[g].ctx;
+                auto ok = [&](int rc) { if (rc != MI_BLUR_OK && feed_rc[g] == MI_BLUR_OK) feed_rc[g] = rc; return rc == MI_BLUR_OK; };
+                {
+                    long long b, e;
+                    mi_blur_shard_range(BATCH_SIZE, g, G, &b, &e);
+                    const int nw = (int)std::min<long long>(e - b, 4);
+                    if (nw > 0) {
+                        rep.run(gin[g][0], original_image, image_size, nw);
+                        ok(mi_blur_submit(ctx, gin[g][0], gout[g][0], nw)) && ok(mi_blur_sync(ctx, nullptr));
+                        mi_blur_reset_timing(ctx);
+                    }
+                }
+                at_gate.fetch_add(1);
+                while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+                long long k = 0;                                      // this feeder's submits so far
+                for (int batch = 0; batch < NUM_BATCHES && feed_rc[g] == MI_BLUR_OK; batch++) {
+                    const int batch_start = batch * BATCH_SIZE;
+                    const int batch_count = std::min(BATCH_SIZE, NUM_IMAGES - batch_start);
+                    long long b, e;
+                    mi_blur_shard_range(batch_count, g, G, &b, &e);
+                    const int n = (int)(e - b);
+                    if (g == 0 && opt.verbose) printf("=== Processing Batch %d/%d === (GPU 0 share: %d images)\n", batch + 1, NUM_BATCHES, n);
+                    if (n <= 0) continue;
+                    const int s = (int)(k % nslots);
+                    if (k >= nslots) {                                // the buffer set was last used by submit k - nslots
+                        if (!ok(mi_blur_wait_oldest(ctx))) break;
+                        if (g == 0 && opt.save.size() && first_output.empty() && k == nslots)
+                            first_output.assign(gout[0][0], gout[0][0] + image_size);
+                    }
+                    rep.run(gin[g][s], original_image, image_size, n);       // create batch image stream (:439-442)
+                    if (!ok(mi_blur_submit(ctx, gin[g][s], gout[g][s], n))) break;
+                    k++;
+                }
+                ok(mi_blur_sync(ctx, &gpus[g].tm));                     // clFinish (:538-539)
+            });
+        }
+        while (at_gate.load() < G) std::this_thread::yield();
+        time_start_total = get_time_ms();
+        go.store(true, std::memory_order_release);
+        for (auto &t : feeders) t.join();
+        for (int g = 0; g < G; g++) mi_check(feed_rc[g], "GPU feeder failed");
+        total_images_gpu = NUM_IMAGES;
+        if (opt.save.size() && first_output.empty()) first_output.assign(gout[0][0], gout[0][0] + image_size);
+    } else if (opt.resident) {
         // one host thread per GPU: a stream of batch-35 launches is issue-rate-bound, so one thread feeding
         // G GPUs in turn would serialise them
         std::vector<std::thread> feeders;
@@ -196,6 +288,7 @@ int main(int argc, char **argv)
             mi_blur_shard_range(NUM_IMAGES, g, G, &b, &e);
             total_images_gpu += (int)(e - b);
             feeders.emplace_back([&, g, b, e]() {
+                mi_blur_bind_thread_to_device(hip_ordinal(g));
                 feed_rc[g] = opt.fused ? mi_blur_resident_run_fused(gpus[g].ctx, (int)(e - b), BATCH_SIZE, 1)
                                        : mi_blur_resident_run(gpus[g].ctx, (int)(e - b), BATCH_SIZE, resident_timed_every);
             });
@@ -367,7 +460,138 @@ int main(int argc, char **argv)
 
     // ---------------- cleanup (heterogeneous_blur.c:727-747)
     for (int s = 0; s < nslots; s++) { mi_blur_host_free(batch_input[s]); mi_blur_host_free(batch_output[s]); }
+    for (int g = 0; g < G; g++) for (size_t s = 0; s < gin[g].size(); s++) { mi_blur_host_free(gin[g][s]); mi_blur_host_free(gout[g][s]); }
     if (cpu.ctx) mi_blur_destroy(cpu.ctx);
     for (auto &d : gpus) mi_blur_destroy(d.ctx);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// --frames: distinct frames in, blurred frames out.  What the reference does once for its one input image —
+// decode through CImg into PLANAR storage, interleave on one host core (heterogeneous_blur.c:106-135), and for the one
+// frame it saves the way back (split_image_blur.c:40-56) — becomes a per-frame stage here, so it is built as a pipeline:
+//   helper threads (on the GPU's socket)   decode batch k+1 into a pinned PLANAR batch buffer, save batch k-S
+//   GPU, inside mi_blur_submit_planar      repack-in kernel reads the planar frames over the host link -> interleaved batch
+//                                          in HBM -> blur -> D2H (or repack-out kernel -> planar frames in pinned memory)
+// `S` buffer sets rotate per device; batch k goes to GPU k % G.
+// ------------------------------------------------------------------------------------------------------------------
+static int run_frames(const Options &opt, int mode, int BATCH_SIZE, const std::vector<std::string> &files)
+{
+    const int N = (int)files.size();
+    if (BATCH_SIZE > N) BATCH_SIZE = N;
+    const int NB = (N + BATCH_SIZE - 1) / BATCH_SIZE;
+    int width = 0, height = 0, channels = 0;
+    if (!probe_frame(files[0], width, height, channels)) { printf("Error: cannot read frame %s\n", files[0].c_str()); return -1; }
+    const int radius = opt.ksize == 3 ? 1 : 2;
+    const size_t image_size = (size_t)width * height * channels;
+    printf("Frame geometry (from %s): %dx%d, %d channels, %zu bytes\n", files[0].c_str(), width, height, channels, image_size);
+    const int G = mode == 1 ? 1 : opt.gpus;
+    if (mode == 2 && !gpus_available(G)) { printf("Error: Could not find %d GPU device(s) (%d visible)\n", G < 1 ? 1 : G, mi_blur_device_count()); return -1; }
+    const int per_dev_slots = opt.slots_given ? opt.slots : 3;
+    const int S = per_dev_slots * G;
+    std::vector<mi_blur_ctx *> ctx(G, nullptr);
+    for (int g = 0; g < G; g++) {
+        mi_check(mi_blur_create(&ctx[g], mode == 1 ? MI_BLUR_DEVICE_CPU : hip_ordinal(g), width, height, channels, radius, BATCH_SIZE, per_dev_slots,
+                                opt.threads), "Failed to create context");
+        if (mode == 2) { printf("GPU device: HIP device %d\n", hip_ordinal(g)); report_placement(g, hip_ordinal(g), g == 0); }
+        else printf("CPU device: host threads\n");
+    }
+    std::vector<uint8_t *> in(S, nullptr), out(S, nullptr);
+    for (int s = 0; s < S; s++) {
+        const int g = s % G;
+        in[s] = (uint8_t *)(mode == 2 ? mi_blur_host_alloc_on(hip_ordinal(g), (size_t)BATCH_SIZE * image_size) : mi_blur_host_alloc((size_t)BATCH_SIZE * image_size));
+        out[s] = (uint8_t *)(mode == 2 ? mi_blur_host_alloc_on(hip_ordinal(g), (size_t)BATCH_SIZE * image_size) : mi_blur_host_alloc((size_t)BATCH_SIZE * image_size));
+        if (!in[s] || !out[s]) { printf("Error: Failed to allocate batch memory\n"); return -1; }
+    }
+    if (!opt.save_dir.empty()) mkdir(opt.save_dir.c_str(), 0777);
+    TaskPool pool(opt.host_threads, mode == 2 ? hip_ordinal(0) : -1);
+    std::vector<std::vector<uint8_t>> scratch(pool.threads());
+    std::vector<double> decode_ms(pool.threads(), 0.0), save_ms(pool.threads(), 0.0);
+    std::atomic<int> failed{0};
+    auto out_name = [&](int i) {
+        std::string base = files[i].substr(files[i].find_last_of('/') == std::string::npos ? 0 : files[i].find_last_of('/') + 1);
+        const size_t dot = base.rfind('.');
+        if (dot != std::string::npos) base.resize(dot);
+#ifdef MI_BLUR_WITH_CIMG
+        return opt.save_dir + "/" + base + ".bmp";
+#else
+        return opt.save_dir + "/" + base + (channels == 3 ? ".ppm" : ".pgm");
+#endif
+    };
+    auto batch_range = [&](int k, int &first, int &n) { first = k * BATCH_SIZE; n = std::min(BATCH_SIZE, N - first); };
+
+    printf("\nStarting frame stream: %d frames in %d batches of up to %d, %d helper thread(s), %d buffer set(s) per device%s%s\n\n", N, NB, BATCH_SIZE,
+           pool.threads(), per_dev_slots, opt.planar_out ? ", planar output" : "", opt.save_dir.empty() ? "" : ", saving every frame");
+    const double t0 = get_time_ms();
+    double wait_ms = 0;
+    for (int k = 0; k < NB + S; k++) {
+        const int s = k % S;
+        int old_first = 0, old_n = 0, first = 0, n = 0;
+        const bool have_old = k >= S && k - S < NB, have_new = k < NB;
+        if (have_old) {                      // batch k-S used this buffer set: its output must be in host memory before it is saved / reused
+            const double w0 = get_time_ms();
+            mi_check(mi_blur_wait_oldest(ctx[(k - S) % G]), "wait failed");
+            wait_ms += get_time_ms() - w0;
+            batch_range(k - S, old_first, old_n);
+        }
+        if (have_new) batch_range(k, first, n);
+        const int n_save = (have_old && !opt.save_dir.empty()) ? old_n : 0;
+        pool.run(n_save + (have_new ? n : 0), [&](int item, int t) {
+            const double a = get_time_ms();
+            if (item < n_save) {
+                if (!save_frame(out_name(old_first + item), out[s] + (size_t)item * image_size, width, height, channels, opt.planar_out, scratch[t])) failed++;
+                save_ms[t] += get_time_ms() - a;
+            } else {
+                const int j = item - n_save;
+                if (!decode_frame_planar(files[first + j], in[s] + (size_t)j * image_size, width, height, channels, scratch[t])) failed++;
+                decode_ms[t] += get_time_ms() - a;
+            }
+        });
+        if (failed.load()) {
+            printf("Error: a frame could not be read (or differs from %dx%dx%d) or written\n", width, height, channels);
+            for (auto c : ctx) { (void)mi_blur_sync(c, nullptr); mi_blur_destroy(c); }        // work already submitted drains first
+            for (int q = 0; q < S; q++) { mi_blur_host_free(in[q]); mi_blur_host_free(out[q]); }
+            return -1;
+        }
+        if (have_new) {
+            if (opt.verbose) printf("  Batch %d/%d: frames %d-%d -> device %d\n", k + 1, NB, first, first + n - 1, k % G);
+            mi_check(mi_blur_submit_planar(ctx[k % G], in[s], out[s], n, opt.planar_out ? 1 : 0), "submit failed");
+        }
+    }
+    DeviceTimes td;
+    uint64_t bytes_alg = 0, launches = 0;
+    for (int g = 0; g < G; g++) { mi_blur_timing tm{}; mi_check(mi_blur_sync(ctx[g], &tm), "sync failed"); td.add(tm); bytes_alg += tm.bytes_alg; launches += tm.launches; }
+    const double wall = get_time_ms() - t0;
+    printf("All batches finished!\n\n");
+    double dsum = 0, ssum = 0;
+    for (double v : decode_ms) dsum += v;
+    for (double v : save_ms) ssum += v;
+    report_header(BATCH_SIZE, wall, N);
+    report_device(mode == 1 ? 2 : 3, mode == 1 ? "CPU" : "GPU", ("processed " + std::to_string(N) + " frames").c_str(), td, N);
+    printf("\n====================\n\n");
+    const Throughput thr = report_throughput(N, width, height, wall);
+    printf("10. FRAME INGEST (distinct frames; ingest-inclusive figures)\n");
+    printf("   Frames: %d files, decoded into pinned PLANAR batch buffers by %d helper thread(s)\n", N, pool.threads());
+    printf("   Decode:            %.2f ms of helper-thread time (%.4f ms per frame)\n", dsum, dsum / N);
+    if (mode == 2) {
+        printf("   GPU repack-in:     %.2f ms (planar frames read over the host link, interleaved batch written to HBM)\n", td.in_ms);
+        printf("   GPU blur:          %.2f ms\n", td.kernel_ms);
+        printf("   GPU %s %.2f ms\n", opt.planar_out ? "repack-out:   " : "copy-out:     ", td.out_ms);
+    } else {
+        printf("   CPU repack + blur: %.2f ms\n", td.kernel_ms);
+    }
+    if (!opt.save_dir.empty()) printf("   Save:              %.2f ms of helper-thread time (%.4f ms per frame) -> %s\n", ssum, ssum / N, opt.save_dir.c_str());
+    printf("   Host blocked waiting for a device: %.2f ms of %.2f ms wall\n", wait_ms, wall);
+    printf("   Ingest-inclusive throughput: %.2f images/sec (%.2f Megapixels/sec)\n\n", thr.img_s, thr.mpix);
+    Roofline rf;
+    if (mode == 2) { rf = report_roofline(9, G, bytes_alg, launches, td.kernel_ms, N); printf("\n"); }
+    if (!opt.csv.empty()) {
+        DeviceTimes none;
+        Comparison cmp;
+        append_csv(opt.csv, BATCH_SIZE, mode == 1 ? "cpu-frames" : "gpu-frames", mode == 1 ? 0.f : 1.f, N, NB, width, height, wall, mode == 1 ? N : 0,
+                   mode == 1 ? td : none, mode == 2 ? N : 0, mode == 2 ? td : none, cmp, thr, 0.0, rf, mode == 2 ? G : 0);
+    }
+    for (int s = 0; s < S; s++) { mi_blur_host_free(in[s]); mi_blur_host_free(out[s]); }
+    for (auto c : ctx) mi_blur_destroy(c);
     return 0;
 }

@@ -13,6 +13,8 @@
 
 #include "mi_blur.h"
 
+#include <dirent.h>
+#include <sys/stat.h>
 #include <sys/time.h>
 
 #include <atomic>
@@ -23,6 +25,7 @@
 #include <cstring>
 #include <functional>
 #include <mutex>
+#include <algorithm>
 #include <string>
 #include <thread>
 #include <vector>
@@ -154,6 +157,7 @@ struct Options {
     int syn_w = 320, syn_h = 240, syn_c = 3;   // --size WxH, --channels C
     int ksize = 3;                       // --ksize 3|5
     int images = 5000;                   // --images N   (NUM_IMAGES, heterogeneous_blur.c:44)
+    bool images_given = false;
     int gpus = 1;                        // --gpus G
     bool slots_given = false;
     int slots = 2;                       // --slots S    staging slots / batch buffers in flight (2 measured best:
@@ -174,6 +178,10 @@ struct Options {
     std::string transport = "rccl";      // --transport rccl|p2p  (split_image_blur --resident): halo rows by RCCL or peer copies
     bool auto_ratio = false;             // gpu_ratio given as "auto": calibrate on the first batches (heterogeneous_blur both)
     bool size_given = false;
+    std::string frames;                  // --frames DIR|PATTERN|FILE  (heterogeneous_blur cpu|gpu): a stream of DISTINCT frames, decoded
+                                         //              by the helper threads into pinned PLANAR batch buffers, repacked on the GPU
+    std::string save_dir;                // --save-dir DIR   (with --frames) write every blurred frame as DIR/<name>.ppm|.pgm
+    bool planar_out = false;             // --planar-out     (with --frames) outputs come back planar (GPU repack-out kernel)
 };
 
 // Returns the number of leading positional arguments (those before the first "--flag").
@@ -192,7 +200,7 @@ inline int parse_flags(int argc, char **argv, Options &o)
         else if (a == "--size") { if (sscanf(next("--size"), "%dx%d", &o.syn_w, &o.syn_h) != 2 || o.syn_w <= 0 || o.syn_h <= 0) { printf("Error: --size WxH\n"); exit(-1); } o.synthetic = true; o.size_given = true; }
         else if (a == "--channels") o.syn_c = atoi(next("--channels"));
         else if (a == "--ksize") { o.ksize = atoi(next("--ksize")); if (o.ksize != 3 && o.ksize != 5) { printf("Error: --ksize must be 3 or 5\n"); exit(-1); } }
-        else if (a == "--images") { o.images = atoi(next("--images")); if (o.images < 1) { printf("Error: --images must be >= 1\n"); exit(-1); } }
+        else if (a == "--images") { o.images = atoi(next("--images")); if (o.images < 1) { printf("Error: --images must be >= 1\n"); exit(-1); } o.images_given = true; }
         else if (a == "--gpus") o.gpus = atoi(next("--gpus"));
         else if (a == "--slots") { o.slots = atoi(next("--slots")); if (o.slots < 1) o.slots = 1; o.slots_given = true; }
         else if (a == "--threads") o.threads = atoi(next("--threads"));
@@ -206,6 +214,9 @@ inline int parse_flags(int argc, char **argv, Options &o)
         else if (a == "--iterate") o.iterate = true;
         else if (a == "--overlap") o.overlap = true;
         else if (a == "--fused") o.fused = true;
+        else if (a == "--frames") o.frames = next("--frames");
+        else if (a == "--save-dir") o.save_dir = next("--save-dir");
+        else if (a == "--planar-out") o.planar_out = true;
         else if (a == "--transport") { o.transport = next("--transport"); if (o.transport != "rccl" && o.transport != "p2p") { printf("Error: --transport rccl|p2p\n"); exit(-1); } }
         else { printf("Error: unknown option %s\n", a.c_str()); exit(-1); }
     }
@@ -221,6 +232,21 @@ inline bool virtual_gpus() { const char *e = getenv("MI_BLUR_VIRTUAL_GPUS"); ret
 inline int hip_ordinal(int g) { const int n = mi_blur_device_count(); return virtual_gpus() && n > 0 ? g % n : g; }
 inline bool gpus_available(int G) { const int n = mi_blur_device_count(); return n >= 1 && G >= 1 && (G <= n || virtual_gpus()); }
 
+// Host placement banner: which CPUs the feeder / batch-building threads of a GPU keep to (its socket's), from sysfs.
+// Binds the CALLING thread as a side effect when `bind` is set.  One line per GPU; tests parse it.
+inline void report_placement(int g, int ordinal, bool bind)
+{
+    char list[512] = "";
+    int node = -1;
+    const int rc = mi_blur_device_cpulist(ordinal, list, sizeof list, &node);
+    const char *off = getenv("MI_BLUR_NO_AFFINITY");
+    if (off && atoi(off) != 0) { printf("GPU %d host placement: not pinned (MI_BLUR_NO_AFFINITY set)\n", g); return; }
+    if (rc != MI_BLUR_OK || !list[0]) { printf("GPU %d host placement: not pinned (topology not exposed by sysfs)\n", g); return; }
+    const int n = bind ? mi_blur_bind_thread_to_device(ordinal) : -1;
+    if (bind && n == 0) { printf("GPU %d host placement: not pinned (no allowed CPU among %s)\n", g, list); return; }
+    printf("GPU %d host placement: feeder + batch-building threads and pinned buffers on CPUs %s (NUMA node %d)\n", g, list, node);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Batch stream construction (heterogeneous_blur.c:439-442: memcpy of the source image into every slot of the
 // batch buffer, inside the timed region).  At MI355X speeds this single-threaded memcpy is the slowest stage of
@@ -229,9 +255,11 @@ inline bool gpus_available(int G) { const int n = mi_blur_device_count(); return
 // ------------------------------------------------------------------------------------------------
 class Replicator {
 public:
-    explicit Replicator(int n_threads) : n_(n_threads < 1 ? 1 : n_threads)
+    // device >= 0: the helper threads keep to the CPUs of that GPU's socket (mi_blur_bind_thread_to_device) — they write
+    // the batch buffers that GPU reads
+    explicit Replicator(int n_threads, int device = -1) : n_(n_threads < 1 ? 1 : n_threads)
     {
-        for (int i = 1; i < n_; i++) workers_.emplace_back([this, i] { loop(i); });
+        for (int i = 1; i < n_; i++) workers_.emplace_back([this, i, device] { if (device >= 0) mi_blur_bind_thread_to_device(device); loop(i); });
     }
     ~Replicator()
     {
@@ -272,6 +300,161 @@ private:
     unsigned long long gen_ = 0;
     bool stop_ = false;
     uint8_t *dst_ = nullptr; const uint8_t *src_ = nullptr; size_t size_ = 0; int count_ = 0, pending_ = 0;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Frame source: a stream of DISTINCT frames instead of one image copied N times.  The reference's loader,
+// CImg, stores a frame PLANAR and the reference interleaves it on one host core (heterogeneous_blur.c:106-135); here the
+// decoder threads only produce the planar frame — in a pinned batch buffer — and the interleave is a GPU kernel inside
+// mi_blur_submit_planar.  PPM/PGM always; anything CImg reads when built with -DMI_BLUR_WITH_CIMG.
+// ------------------------------------------------------------------------------------------------
+inline bool is_dir(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode); }
+inline bool is_file(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode); }
+
+inline bool frame_extension(const std::string &name)
+{
+    const size_t dot = name.rfind('.');
+    if (dot == std::string::npos) return false;
+    std::string e = name.substr(dot + 1);
+    for (auto &ch : e) ch = (char)tolower(ch);
+    if (e == "ppm" || e == "pgm") return true;
+#ifdef MI_BLUR_WITH_CIMG
+    if (e == "jpg" || e == "jpeg" || e == "bmp" || e == "png") return true;
+#endif
+    return false;
+}
+
+// DIR -> its frame files in name order; "f_%04d.ppm" -> f_0000.ppm, f_0001.ppm, ... while they exist; FILE -> that file
+inline std::vector<std::string> list_frames(const std::string &arg)
+{
+    std::vector<std::string> files;
+    if (is_dir(arg)) {
+        if (DIR *d = opendir(arg.c_str())) {
+            while (struct dirent *e = readdir(d))
+                if (frame_extension(e->d_name) && is_file(arg + "/" + e->d_name)) files.push_back(arg + "/" + e->d_name);
+            closedir(d);
+        }
+        std::sort(files.begin(), files.end());
+    } else if (arg.find('%') != std::string::npos) {
+        for (int i = 0;; i++) {
+            char path[4096];
+            snprintf(path, sizeof path, arg.c_str(), i);
+            if (!is_file(path)) break;
+            files.push_back(path);
+        }
+    } else if (is_file(arg)) {
+        files.push_back(arg);
+    }
+    return files;
+}
+
+// Header only (the first frame fixes the stream's geometry).
+inline bool probe_frame(const std::string &path, int &w, int &h, int &c)
+{
+#ifdef MI_BLUR_WITH_CIMG
+    try { cimg_library::CImg<unsigned char> ci(path.c_str()); w = ci.width(); h = ci.height(); c = ci.spectrum(); return true; } catch (...) {}
+#endif
+    Image img;
+    if (!load_pnm(path.c_str(), img)) return false;
+    w = img.width; h = img.height; c = img.channels;
+    return true;
+}
+
+// One frame into `planar` (c*w*h bytes, CImg order).  `scratch` is the calling thread's own buffer.
+inline bool decode_frame_planar(const std::string &path, uint8_t *planar, int w, int h, int c, std::vector<uint8_t> &scratch)
+{
+#ifdef MI_BLUR_WITH_CIMG
+    try {
+        cimg_library::CImg<unsigned char> ci(path.c_str());
+        if (ci.width() != w || ci.height() != h || ci.spectrum() != c) return false;
+        memcpy(planar, ci.data(), (size_t)w * h * c);           // CImg storage IS planar
+        return true;
+    } catch (...) {}
+#endif
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char magic[3] = {0, 0, 0};
+    int fw = 0, fh = 0, maxv = 0;
+    bool ok = fread(magic, 1, 2, f) == 2 && magic[0] == 'P' && (magic[1] == '6' || magic[1] == '5') && skip_ws_comments(f) &&
+              fscanf(f, "%d", &fw) == 1 && skip_ws_comments(f) && fscanf(f, "%d", &fh) == 1 && skip_ws_comments(f) &&
+              fscanf(f, "%d", &maxv) == 1 && maxv == 255 && fw == w && fh == h && (magic[1] == '6' ? 3 : 1) == c;
+    if (ok) {
+        fgetc(f);
+        const size_t plane = (size_t)w * h;
+        if (c == 1) ok = fread(planar, 1, plane, f) == plane;                  // one plane: already "planar"
+        else {
+            scratch.resize(plane * c);
+            ok = fread(scratch.data(), 1, scratch.size(), f) == scratch.size();
+            if (ok)
+                for (int k = 0; k < c; k++) {                                    // what CImg's PNM reader does: scatter into planes
+                    uint8_t *dst = planar + (size_t)k * plane;
+                    const uint8_t *src = scratch.data() + k;
+                    for (size_t px = 0; px < plane; px++) dst[px] = src[px * c];
+                }
+        }
+    }
+    fclose(f);
+    return ok;
+}
+
+// Save one output frame; `planar` says how `px` is laid out (split_image_blur.c:40-56 builds the planar form to save).
+inline bool save_frame(const std::string &path, const uint8_t *px, int w, int h, int c, bool planar, std::vector<uint8_t> &scratch)
+{
+#ifdef MI_BLUR_WITH_CIMG
+    if (planar) { cimg_library::CImg<unsigned char> out(px, w, h, 1, c); out.save(path.c_str()); return true; }
+#endif
+    if (!planar || c == 1) return save_pnm(path.c_str(), px, w, h, c);
+    const size_t plane = (size_t)w * h;
+    scratch.resize(plane * c);
+    for (int k = 0; k < c; k++)
+        for (size_t i = 0; i < plane; i++) scratch[i * c + k] = px[(size_t)k * plane + i];
+    return save_pnm(path.c_str(), scratch.data(), w, h, c);
+}
+
+// A few persistent helper threads running fn(item, thread) over items [0, n): frame decode / save tasks.
+class TaskPool {
+public:
+    explicit TaskPool(int n_threads, int device = -1) : n_(n_threads < 1 ? 1 : n_threads)
+    {
+        for (int i = 1; i < n_; i++) workers_.emplace_back([this, i, device] { if (device >= 0) mi_blur_bind_thread_to_device(device); loop(i); });
+    }
+    ~TaskPool()
+    {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; gen_++; }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    int threads() const { return n_; }
+    void run(int n_items, const std::function<void(int, int)> &fn)
+    {
+        if (n_items <= 0) return;
+        { std::lock_guard<std::mutex> lk(m_); fn_ = &fn; items_ = n_items; next_.store(0); pending_ = n_ - 1; gen_++; }
+        cv_.notify_all();
+        work(0);
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+    }
+
+private:
+    void work(int t) { for (int i; (i = next_.fetch_add(1)) < items_;) (*fn_)(i, t); }
+    void loop(int t)
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [&] { return gen_ != seen; }); seen = gen_; if (stop_) return; }
+            work(t);
+            { std::lock_guard<std::mutex> lk(m_); if (--pending_ == 0) done_.notify_one(); }
+        }
+    }
+    const int n_;
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    unsigned long long gen_ = 0;
+    bool stop_ = false;
+    const std::function<void(int, int)> *fn_ = nullptr;
+    int items_ = 0, pending_ = 0;
+    std::atomic<int> next_{0};
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -131,6 +131,9 @@ int main(int argc, char **argv)
         p.name = "HIP device " + std::to_string(hip_ordinal(g));
         printf("GPU device: %s (rows %d-%d)\n", p.name.c_str(), p.out_row0, p.out_row0 + p.out_rows - 1);
     }
+    // every device reads the SAME batch buffer here (one image split by rows, split_image_blur.c:469-480), built by this
+    // one thread: it and its helpers keep to GPU 0's socket, where mi_blur_host_alloc pins the buffer
+    for (int g = 0; g < G; g++) report_placement(g, hip_ordinal(g), g == 0);
     printf("\nKernel objects created\n\n");
 
     printf("Allocating device buffers...\n");
@@ -148,7 +151,7 @@ int main(int argc, char **argv)
     // ---------------- batch processing (split_image_blur.c:441-607)
     printf("Starting batch processing of %d images in %d batches...\n\n", NUM_IMAGES, NUM_BATCHES);
     std::vector<uint8_t> first_output;
-    Replicator replicate(opt.host_threads);
+    Replicator replicate(opt.host_threads, hip_ordinal(0));
     const double time_start_total = get_time_ms();
     for (int batch = 0; batch < NUM_BATCHES; batch++) {
         if (opt.verbose) printf("=== Processing Batch %d/%d ===\n", batch + 1, NUM_BATCHES);

@@ -828,7 +828,7 @@ static std::mutex &tunables_mutex() { static std::mutex m; return m; }
 static Tunables &tunables_storage()
 {
     static Tunables t = [] {
-        Tunables v{1, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0, 4, 24, 1, 1, 8, 0, 8};  // rpg 0 / stream_bh 0 = choose per launch
+        Tunables v{1, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0, 4, 24, 1, 1, 8, 0, 8, 1};  // rpg 0 / stream_bh 0 = choose per launch
         if (const char *e = getenv("MI_BLUR_STAGE")) v.stage_dma = strcmp(e, "reg") != 0;
         if (const char *e = getenv("MI_BLUR_RPG")) { const int r = atoi(e); v.rpg = (r == 4 || r == 8 || r == 16) ? r : 0; }
         if (const char *e = getenv("MI_BLUR_XCD")) v.xcd_remap = atoi(e) != 0;

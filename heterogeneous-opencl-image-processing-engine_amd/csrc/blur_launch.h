@@ -68,6 +68,8 @@ struct Tunables {
     int direct_bh;       // direct variant: output rows per lane (8; 4 | 12 | 16 instantiated for C = 3 only, A/B runs)
     int debug_xcd_times; // diagnostics: the tiled kernel's workgroups leave start/end times per XCD (mi_blur_debug_xcd_times)
     int fused_window;    // fused stream: batches per window of its blockIdx -> tile map (8: one whole batch per XCD per window)
+    int zero_copy_events; // zero-copy submits: 1 = the dispatch carries start/stop timestamp events (kernel bucket + completion),
+                         // 0 = plain launch, completion by stream synchronise (timing experiment: no kernel bucket)
 };
 Tunables tunables();
 unsigned long long *debug_xcd_buffer();

@@ -194,6 +194,28 @@ void copy_blocks(uint8_t *dst, size_t dst_stride, const uint8_t *src, size_t src
     });
 }
 
+// The reference's host loops (heterogeneous_blur.c:125-134 in, split_image_blur.c:40-56 out), over images on pool threads.
+void cpu_repack(const uint8_t *src, uint8_t *dst, int W, int H, int C, int n_images, bool p2i, int n_threads)
+{
+    if (n_images <= 0) return;
+    if (n_threads <= 0) n_threads = hardware_threads();
+    const size_t plane = (size_t)W * H, isz = plane * C;
+    std::atomic<int> next{0};
+    Pool::get().run(std::min(n_threads, n_images), [&](int) {
+        for (;;) {
+            const int i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n_images) break;
+            const uint8_t *s = src + (size_t)i * isz;
+            uint8_t *d = dst + (size_t)i * isz;
+            for (int c = 0; c < C; c++)
+                for (size_t px = 0; px < plane; px++) {
+                    if (p2i) d[px * C + c] = s[(size_t)c * plane + px];
+                    else d[(size_t)c * plane + px] = s[px * C + c];
+                }
+        }
+    });
+}
+
 uint64_t fnv1a64(const uint8_t *p, size_t n)
 {
     uint64_t h = 0xcbf29ce484222325ull;

@@ -10,6 +10,7 @@
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <chrono>
@@ -98,6 +99,7 @@ extern "C" int mi_blur_set_option(const char *key, int value)
     else if (!strcmp(key, "direct_bh")) { if (value != 4 && value != 8 && value != 12 && value != 16) return MI_BLUR_ERR_INVALID; t.direct_bh = value; }
     else if (!strcmp(key, "fused_window")) { if (value < 1 || value > 4096) return MI_BLUR_ERR_INVALID; t.fused_window = value; }
     else if (!strcmp(key, "debug_xcd_times")) t.debug_xcd_times = value != 0;
+    else if (!strcmp(key, "zero_copy_events")) t.zero_copy_events = value != 0;
     else if (!strcmp(key, "xcd_run")) { if (value < 0 || value > (1 << 20)) return MI_BLUR_ERR_INVALID; t.xcd_run = value; }
     else return MI_BLUR_ERR_INVALID;
     set_tunables(t);
@@ -167,6 +169,8 @@ struct Slot {
     int out_n = 0;
     bool out_staged = false;
     bool zero_copy = false;                               // in flight on the context's zero-copy stream
+    bool zc_plain = false;                                // ... as a plain launch without events (experiment)
+    hipStream_t zc_stream = nullptr;
 };
 
 struct TimedLaunch { hipEvent_t s, e; };
@@ -246,6 +250,98 @@ extern "C" void mi_blur_host_free(void *p)
     free(p);
 }
 
+// ----------------------------------------------------------------------------------
+// NUMA placement of per-GPU host work.  The reference drives both of its devices from one
+// host thread on a one-socket desktop (heterogeneous_blur.c:482-539); an 8-GPU MI355X node has two sockets with four
+// GPUs each, and a feeder thread, a batch-building memcpy or a pinned buffer on the other socket puts every byte of
+// the stream on the inter-socket link first.  No libnuma: the GPU's PCI bus id -> sysfs local_cpulist -> sched_setaffinity.
+// ----------------------------------------------------------------------------------
+static bool affinity_disabled()
+{
+    const char *e = getenv("MI_BLUR_NO_AFFINITY");
+    return e && atoi(e) != 0;
+}
+
+// "0-63,128-191" -> cpu_set_t; false when the text holds no CPU
+static bool parse_cpulist(const char *text, cpu_set_t *set)
+{
+    CPU_ZERO(set);
+    bool any = false;
+    for (const char *p = text; *p;) {
+        char *end = nullptr;
+        long a = strtol(p, &end, 10);
+        if (end == p) break;
+        long b = a;
+        if (*end == '-') { p = end + 1; b = strtol(p, &end, 10); if (end == p) break; }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++) if (c >= 0) { CPU_SET((int)c, set); any = true; }
+        p = end;
+        while (*p == ',' || *p == ' ' || *p == '\n') p++;
+    }
+    return any;
+}
+
+static int device_sysfs(int device, const char *leaf, char *buf, size_t n)
+{
+    if (!buf || n == 0) return MI_BLUR_ERR_INVALID;
+    buf[0] = 0;
+    const int ndev = mi_blur_device_count();
+    if (ndev <= 0 || device < 0 || device >= ndev) return MI_BLUR_ERR_NO_DEVICE;
+    char bdf[64] = {0};
+    HIP_TRY(hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device));
+    for (char *q = bdf; *q; q++) if (*q >= 'A' && *q <= 'F') *q = (char)(*q - 'A' + 'a');     // sysfs spells it in lower case
+    char path[160];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/%s", bdf, leaf);
+    FILE *f = fopen(path, "r");
+    if (!f) return MI_BLUR_ERR_UNSUPPORTED;
+    const bool ok = fgets(buf, (int)n, f) != nullptr;
+    fclose(f);
+    if (!ok) { buf[0] = 0; return MI_BLUR_ERR_UNSUPPORTED; }
+    for (size_t i = strlen(buf); i > 0 && (buf[i - 1] == '\n' || buf[i - 1] == ' '); i--) buf[i - 1] = 0;
+    return MI_BLUR_OK;
+}
+
+extern "C" int mi_blur_device_cpulist(int device, char *buf, size_t n, int *numa_node)
+{
+    if (numa_node) {
+        char nb[32];
+        *numa_node = device_sysfs(device, "numa_node", nb, sizeof nb) == MI_BLUR_OK ? atoi(nb) : -1;
+    }
+    return device_sysfs(device, "local_cpulist", buf, n);
+}
+
+extern "C" int mi_blur_bind_thread_to_device(int device)
+{
+    if (affinity_disabled()) return 0;
+    char list[512];
+    if (device_sysfs(device, "local_cpulist", list, sizeof list) != MI_BLUR_OK) return 0;
+    cpu_set_t local, allowed, both;
+    if (!parse_cpulist(list, &local)) return 0;
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return 0;
+    CPU_AND(&both, &local, &allowed);
+    const int n = CPU_COUNT(&both);
+    if (n == 0) return 0;                                        // a cpuset that excludes the GPU's socket: leave the thread alone
+    if (sched_setaffinity(0, sizeof both, &both) != 0) return 0;
+    return n;
+}
+
+extern "C" void *mi_blur_host_alloc_on(int device, size_t bytes)
+{
+    if (mi_blur_device_count() <= 0) return malloc(bytes);
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    cpu_set_t saved;
+    const bool have_saved = sched_getaffinity(0, sizeof saved, &saved) == 0;
+    // pin + map with the GPU current and from one of its socket's CPUs: the runtime takes the pages from the host pool
+    // nearest the current device, and whatever it leaves to first touch is touched from there as well
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    const int bound = mi_blur_bind_thread_to_device(device);
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+    if (bound > 0 && have_saved) (void)sched_setaffinity(0, sizeof saved, &saved);
+    (void)hipSetDevice(prev);
+    return p;
+}
+
 static void free_slot(Slot &s)
 {
     if (s.h_in) (void)hipHostFree(s.h_in);
@@ -309,6 +405,11 @@ static int finish_slot(mi_blur_ctx *c, Slot &s)
     if (!s.busy) return MI_BLUR_OK;
     float ms = 0.f;
     if (s.zero_copy) {                                           // launched on one of the context's zero-copy streams
+        if (s.zc_plain) {                                        // experiment: no events on the dispatch
+            HIP_TRY(hipStreamSynchronize(s.zc_stream));
+            s.zero_copy = false; s.busy = false; s.zc_plain = false;
+            return MI_BLUR_OK;
+        }
         HIP_TRY(hipEventSynchronize(s.ke));
         float a = 0.f, b = 0.f;
         if (c->zc_ref_valid && hipEventElapsedTime(&a, c->zc_ref, s.ks) == hipSuccess && hipEventElapsedTime(&b, c->zc_ref, s.ke) == hipSuccess && b >= a) {
@@ -466,11 +567,14 @@ static int submit_common(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_o
                 d.in = zin; d.out = zout; d.width = c->W; d.band_rows = band_rows; d.channels = c->C;
                 d.radius = c->R; d.n_images = n_images; d.y0 = y0; d.y1 = y1; d.variant = MI_BLUR_VARIANT_AUTO;
                 d.in_stride = (long long)in_stride; d.out_stride = (long long)out_stride;
-                d.stream = zs; d.start = s.ks; d.stop = s.ke;
+                const bool with_events = tunables().zero_copy_events != 0;
+                d.stream = zs;
+                if (with_events) { d.start = s.ks; d.stop = s.ke; }
+                s.zc_plain = !with_events; s.zc_stream = zs;
                 d.max_blocks = tunables().zero_copy_blocks;
                 // once per sync window, in front of its first launch (and again every ~10 s of a window that never syncs,
                 // so the float milliseconds since the reference keep their resolution)
-                if (!c->zc_ref_valid || c->zc_covered_ms > 10e3) {
+                if (with_events && (!c->zc_ref_valid || c->zc_covered_ms > 10e3)) {
                     if (!c->zc_ref) HIP_TRY(hipEventCreate(&c->zc_ref));
                     HIP_TRY(hipEventRecord(c->zc_ref, zs));
                     c->zc_ref_valid = true; c->zc_covered_ms = 0.0;
@@ -553,6 +657,79 @@ extern "C" int mi_blur_submit_bands(mi_blur_ctx *c, const uint8_t *host_in, uint
     if (n_images == 0) return MI_BLUR_OK;
     return submit_common(c, host_in, host_out, band_rows, n_images, halo_top, band_rows - halo_bottom,
                          host_image_stride, host_image_stride);
+}
+
+// Frames as the reference's loader hands them over: PLANAR (CImg storage).  The reference interleaves every frame on one
+// host core before the stream is built (heterogeneous_blur.c:125-134) and de-interleaves on the way out to save one
+// (split_image_blur.c:40-56); here both repacks are GPU kernels inside the submit.  The repack-in kernel reads the
+// pinned planar frames straight over PCIe (it IS the upload: its duration is the h2d bucket) and writes the
+// interleaved batch into HBM; the blur runs HBM -> HBM; the way out is either a D2H copy of the interleaved batch or the
+// repack-out kernel writing planar frames straight into pinned host memory.  The slot's two device buffers are enough:
+// d_in is free again once the blur has read it, so the planar result is built there.
+extern "C" int mi_blur_submit_planar(mi_blur_ctx *c, const uint8_t *host_planar_in, uint8_t *host_out, int n_images, int planar_out)
+{
+    if (!c || !host_planar_in || !host_out || host_planar_in == host_out) return MI_BLUR_ERR_INVALID;
+    if (n_images < 0 || n_images > c->max_batch) return MI_BLUR_ERR_INVALID;
+    if (n_images == 0) return MI_BLUR_OK;
+    const size_t bytes = c->image_bytes * (size_t)n_images;
+    if (c->is_cpu()) {
+        CpuJob *j = new (std::nothrow) CpuJob;
+        if (!j) return MI_BLUR_ERR_NOMEM;
+        const int W = c->W, H = c->H, C = c->C, R = c->R, nt = c->n_threads;
+        j->th = std::thread([=]() {
+            const auto t0 = std::chrono::steady_clock::now();
+            std::vector<uint8_t> a(bytes), b(planar_out ? bytes : 0);
+            cpu_repack(host_planar_in, a.data(), W, H, C, n_images, true, nt);
+            cpu_blur_batch(a.data(), planar_out ? b.data() : host_out, W, H, C, R, n_images, 0, H, nt);
+            if (planar_out) cpu_repack(b.data(), host_out, W, H, C, n_images, false, nt);
+            j->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        });
+        c->cpu_jobs.push_back(j);
+    } else {
+        HIP_TRY(hipSetDevice(c->device));
+        Slot &s = c->slots[c->next_slot];
+        c->next_slot = (c->next_slot + 1) % (int)c->slots.size();
+        int rc = finish_slot(c, s);
+        if (rc) return rc;
+        s.zero_copy = false;
+        // source the repack-in kernel can read: the caller's frames if they are pinned, the slot's pinned staging otherwise
+        const uint8_t *src = pinned_device_ptr(host_planar_in);
+        if (!src) {
+            copy_blocks(s.h_in, bytes, host_planar_in, bytes, bytes, 1, STAGING_COPY_THREADS);
+            src = pinned_device_ptr(s.h_in);
+            if (!src) return MI_BLUR_ERR_STATE;
+        }
+        uint8_t *dst_pinned = pinned_device_ptr(host_out);
+        s.out_staged = !dst_pinned;
+        s.user_out = host_out; s.out_bytes = bytes; s.out_band = bytes; s.out_stride = bytes; s.out_n = 1;
+        HIP_TRY(hipEventRecord(s.ev[0], s.stream));
+        rc = launch_planar_to_interleaved(src, s.d_in, c->W, c->H, c->C, n_images, s.stream);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(s.ev[1], s.stream));
+        LaunchDesc d{};
+        d.in = s.d_in; d.out = s.d_out; d.width = c->W; d.band_rows = c->H; d.channels = c->C;
+        d.radius = c->R; d.n_images = n_images; d.y0 = 0; d.y1 = c->H; d.variant = MI_BLUR_VARIANT_AUTO;
+        d.stream = s.stream; d.start = s.ks; d.stop = s.ke;
+        d.concurrent = (int)c->slots.size();
+        rc = launch(d);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(s.ev[2], s.stream));
+        if (planar_out) {
+            uint8_t *dst = dst_pinned ? dst_pinned : pinned_device_ptr(s.h_out);
+            if (!dst) return MI_BLUR_ERR_STATE;
+            rc = launch_interleaved_to_planar(s.d_out, dst, c->W, c->H, c->C, n_images, s.stream);
+            if (rc) return rc;
+        } else {
+            HIP_TRY(hipMemcpyAsync(s.out_staged ? s.h_out : host_out, s.d_out, bytes, hipMemcpyDeviceToHost, s.stream));
+        }
+        HIP_TRY(hipEventRecord(s.ev[3], s.stream));
+        s.busy = true;
+        c->tm.bytes_h2d += bytes; c->tm.bytes_d2h += bytes;
+    }
+    c->tm.bytes_alg += 2ull * bytes;
+    c->tm.images += (uint64_t)n_images;
+    c->tm.launches += 1;
+    return MI_BLUR_OK;
 }
 
 // Wait for the OLDEST submit still in flight (its output is then in caller memory), so a host

@@ -168,6 +168,22 @@ void mi_blur_destroy(mi_blur_ctx *ctx);
 void *mi_blur_host_alloc(size_t bytes);
 void mi_blur_host_free(void *p);
 
+/* NUMA placement of per-GPU host work.  The reference drives both of its devices from one host thread of a one-socket
+ * desktop (heterogeneous_blur.c:482-539); an 8-GPU node has two sockets with four GPUs each, and a feeder thread, a
+ * batch-building memcpy (:439-442) or a pinned batch buffer on the other socket puts every byte of the stream on the
+ * inter-socket link first.  No libnuma involved: hipDeviceGetPCIBusId -> /sys/bus/pci/devices/<bdf>/local_cpulist ->
+ * sched_setaffinity.  MI_BLUR_NO_AFFINITY=1 in the environment turns the two binding calls into no-ops.
+ *   mi_blur_device_cpulist         the GPU's local CPU list as sysfs spells it ("0-63,128-191") and its NUMA node
+ *                                  (-1 if unknown); MI_BLUR_ERR_UNSUPPORTED when sysfs does not say
+ *   mi_blur_bind_thread_to_device  restrict the CALLING thread (and threads it starts afterwards) to the GPU's local CPUs
+ *                                  that its current mask allows; returns how many CPUs that is, 0 = nothing was changed
+ *                                  (disabled, unknown topology, or no allowed CPU on that socket)
+ *   mi_blur_host_alloc_on          mi_blur_host_alloc with `device` current and the calling thread on that GPU's socket for
+ *                                  the duration of the call: the buffers of GPU g's feeder belong on GPU g's node */
+int mi_blur_device_cpulist(int device, char *buf, size_t n, int *numa_node);
+int mi_blur_bind_thread_to_device(int device);
+void *mi_blur_host_alloc_on(int device, size_t bytes);
+
 /* Asynchronous H2D -> ONE batched launch -> D2H of n_images images from caller
  * memory.  host_in/host_out must stay valid until mi_blur_sync (the reference
  * frees batch_input/batch_output only after clFinish, heterogeneous_blur.c:538,596-597).
@@ -189,6 +205,15 @@ int mi_blur_submit_band(mi_blur_ctx *ctx, const uint8_t *host_in, uint8_t *host_
  * per-image Write/NDRange/Read on each device (:520-541). */
 int mi_blur_submit_bands(mi_blur_ctx *ctx, const uint8_t *host_in, uint8_t *host_out, int n_images,
                          size_t host_image_stride, int band_rows, int halo_top, int halo_bottom);
+
+/* Frames as the reference's loader hands them over — PLANAR, byte (x, y, c) of frame i at (i*C + c)*W*H + y*W + x (CImg
+ * storage; the reference interleaves each frame on one host core, heterogeneous_blur.c:125-134, and de-interleaves to
+ * save, split_image_blur.c:40-56).  Same contract as mi_blur_submit, with both repacks done by the GPU inside the
+ * submit: the repack-in kernel reads the planar frames over the host link (pinned caller memory is read in place) and
+ * writes the interleaved batch to HBM, the blur runs HBM -> HBM, and host_out receives interleaved frames
+ * (planar_out = 0) or planar ones (planar_out != 0; written straight into pinned caller memory by the repack-out
+ * kernel).  h2d_ms / d2h_ms of such a submit are the repack-in / copy-or-repack-out durations. */
+int mi_blur_submit_planar(mi_blur_ctx *ctx, const uint8_t *host_planar_in, uint8_t *host_out, int n_images, int planar_out);
 
 /* Block until the OLDEST submit still in flight has finished (its output is in caller memory).
  * Lets a host rotate n_slots batch buffers: refill the oldest while the newer ones run. */

@@ -50,6 +50,21 @@ def test_product_does_not_link_the_oracle(pkg):
     assert "import oracle" not in init and "from oracle" not in init and "liboracle" not in init
 
 
+def test_numa_placement_calls_without_a_gpu(pkg, L):
+    """No GPU here: the topology query says so, binding changes nothing, and the placed allocator is plain memory."""
+    if L.mi_blur_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    assert pkg.device_cpulist(0) == ("", -1)
+    buf = C.create_string_buffer(64)
+    assert L.mi_blur_device_cpulist(0, buf, len(buf), None) == pkg.ERR_NO_DEVICE
+    before = os.sched_getaffinity(0)
+    assert L.mi_blur_bind_thread_to_device(0) == 0 and os.sched_getaffinity(0) == before
+    p = L.mi_blur_host_alloc_on(0, 4096)
+    assert p
+    C.memset(p, 7, 4096)
+    L.mi_blur_host_free(p)
+
+
 def test_strerror(L):
     assert L.mi_blur_strerror(0) == b"success"
     assert b"invalid" in L.mi_blur_strerror(-1)

@@ -80,6 +80,84 @@ def test_a1_ksize5_cpu(apps, O, tmp_path):
     assert np.array_equal(read_ppm(tmp_path / "out.ppm"), O.blur(img, 2))
 
 
+def _write_frames(O, d, n, h, w, c, pattern="f_%04d"):
+    os.makedirs(d, exist_ok=True)
+    frames = O.lcg_stream(n, h, w, c, first_index=1000)          # distinct content per frame
+    for i in range(n):
+        write_ppm(os.path.join(d, (pattern % i) + (".ppm" if c == 3 else ".pgm")), frames[i])
+    return frames
+
+
+def _check_saved_frames(O, d, frames, radius, pattern="f_%04d"):
+    want = O.blur_batch(frames, radius)
+    ext = ".ppm" if frames.shape[3] == 3 else ".pgm"
+    for i in range(len(frames)):
+        assert np.array_equal(read_ppm(os.path.join(d, (pattern % i) + ext)), want[i]), f"frame {i}"
+    assert len([f for f in os.listdir(d)]) == len(frames)
+
+
+FRAME_SECTIONS = ["Input frames:", "Frame geometry (from", "Starting frame stream:", "All batches finished!", "1. OVERALL EXECUTION TIME",
+                  "7. THROUGHPUT", "10. FRAME INGEST (distinct frames; ingest-inclusive figures)", "Decode:", "Ingest-inclusive throughput:"]
+
+
+def test_frames_stream_on_the_cpu_device(apps, O, tmp_path):
+    """--frames: a stream of DISTINCT frames (the reference copies one decoded image N times,
+    heterogeneous_blur.c:106-135,439-442).  cpu device here; every saved frame must equal the oracle's blur of ITS input."""
+    het, _ = apps
+    frames = _write_frames(O, tmp_path / "in", 11, 37, 52, 3)
+    r = run([het, "cpu", "0.5", "4", "--frames", "in", "--save-dir", "out"], tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for sct in FRAME_SECTIONS + ["Number of images in stream: 11", "Number of batches: 3", "2. CPU DEVICE (processed 11 frames)", "Save:"]:
+        assert sct in r.stdout, sct
+    _check_saved_frames(O, tmp_path / "out", frames, 1)
+    # printf-style pattern, 5x5, planar output (the save path de-interleaves), grey frames, --images truncates the list
+    grey = _write_frames(O, tmp_path / "g", 9, 40, 48, 1, pattern="g%02d")
+    r = run([het, "cpu", "0.5", "5", "--frames", "g/g%02d.pgm", "--save-dir", "gout", "--ksize", "5", "--planar-out", "--images", "7"], tmp_path)
+    assert r.returncode == 0 and "Number of images in stream: 7" in r.stdout, r.stdout + r.stderr
+    _check_saved_frames(O, tmp_path / "gout", grey[:7], 2, pattern="g%02d")
+    r = run([het, "cpu", "0.5", "4", "--frames", "in", "--save-dir", "out3", "--planar-out"], tmp_path)
+    assert r.returncode == 0
+    _check_saved_frames(O, tmp_path / "out3", frames, 1)
+    # errors: nothing found; both devices at once; a frame of another size in the stream
+    r = run([het, "cpu", "0.5", "4", "--frames", "nowhere"], tmp_path)
+    assert r.returncode != 0 and "Error: no frame files found" in r.stdout
+    r = run([het, "both", "0.5", "4", "--frames", "in"], tmp_path)
+    assert r.returncode != 0 and "use mode cpu or gpu" in r.stdout
+    write_ppm(tmp_path / "in" / "f_0011.ppm", O.lcg_image(20, 20, 3))
+    r = run([het, "cpu", "0.5", "4", "--frames", "in"], tmp_path)
+    assert r.returncode != 0 and "could not be read (or differs from 52x37x3)" in r.stdout
+
+
+@pytest.mark.gpu
+def test_frames_stream_on_the_gpu(apps, O, tmp_path):
+    """--frames on the GPU: helper threads decode into pinned PLANAR batch buffers, the interleave is the GPU's repack-in
+    kernel inside mi_blur_submit_planar (reading the frames over the host link), the blur runs in HBM, and the way out is a
+    copy or the repack-out kernel.  96 distinct frames; every saved frame == oracle blur of its own input."""
+    het, _ = apps
+    frames = _write_frames(O, tmp_path / "in", 96, 256, 256, 3)
+    r = run([het, "gpu", "1.0", "35", "--frames", "in", "--save-dir", "out", "--csv", "f.csv"], tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for sct in FRAME_SECTIONS + ["Number of images in stream: 96", "Number of batches: 3", "3. GPU DEVICE (processed 96 frames)", "GPU repack-in:",
+                                 "GPU blur:", "GPU copy-out:", "9. MI355X KERNEL ROOFLINE", "GPU 0 host placement:"]:
+        assert sct in r.stdout, sct
+    _check_saved_frames(O, tmp_path / "out", frames, 1)
+    row, = read_csv(tmp_path / "f.csv")
+    assert row["mode"] == "gpu-frames" and row["images"] == "96" and float(row["gpu_in_ms"]) > 0 and float(row["gpu_kernel_ms"]) > 0
+    r = run([het, "gpu", "1.0", "20", "--frames", "in", "--save-dir", "out5", "--ksize", "5", "--planar-out", "--slots", "2"], tmp_path)
+    assert r.returncode == 0 and "GPU repack-out:" in r.stdout, r.stdout + r.stderr
+    _check_saved_frames(O, tmp_path / "out5", frames, 2)
+    # two logical GPUs (batch k -> GPU k % 2), grey frames whose plane is not a multiple of 16 pixels (byte repack kernel, ragged blur)
+    grey = _write_frames(O, tmp_path / "g", 40, 167, 250, 1, pattern="g%02d")
+    r = subprocess.run([het, "gpu", "1.0", "7", "--frames", "g", "--save-dir", "gout", "--gpus", "2"], cwd=tmp_path, capture_output=True, text=True,
+                       timeout=600, env=dict(os.environ, MI_BLUR_VIRTUAL_GPUS="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    _check_saved_frames(O, tmp_path / "gout", grey, 1, pattern="g%02d")
+    odd = _write_frames(O, tmp_path / "o", 24, 33, 50, 3, pattern="o%02d")
+    r = run([het, "gpu", "1.0", "10", "--frames", "o", "--save-dir", "oout", "--planar-out"], tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    _check_saved_frames(O, tmp_path / "oout", odd, 1, pattern="o%02d")
+
+
 def test_gpu_modes_fail_loudly_without_gpu(apps, L, tmp_path):
     if L.mi_blur_device_count() > 0:
         pytest.skip("a GPU is visible here")
@@ -174,6 +252,50 @@ def test_a1_gpu_and_both_modes(apps, O, tmp_path):
     assert r.returncode == 0 and "9. MI355X KERNEL ROOFLINE" in r.stdout, r.stdout + r.stderr
     r = run([het, "gpu", "1.0", "35", "--size", "256x256", "--images", "5000", "--resident", "--fused"], tmp_path)
     assert r.returncode == 0 and "one fused dispatch, 143 batches counted in" in r.stdout, r.stdout + r.stderr
+
+
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.split(","):
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+@pytest.mark.gpu
+def test_host_work_is_placed_on_the_gpus_socket(apps, pkg, L, tmp_path):
+    """Feeder threads, batch-building helpers and pinned buffers keep to the CPUs of their GPU's socket (sysfs
+    local_cpulist of the GPU's PCI function); the banner names the list; MI_BLUR_NO_AFFINITY=1 turns it off.  On a one-GPU
+    box this is a no-op for performance, but the whole mechanism runs."""
+    import threading
+    import torch
+    het, spl = apps
+    p = torch.cuda.get_device_properties(0)
+    sysfs = f"/sys/bus/pci/devices/{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+    want_list, want_node = open(sysfs + "/local_cpulist").read().strip(), int(open(sysfs + "/numa_node").read())
+    assert pkg.device_cpulist(0) == (want_list, want_node)
+    local = _parse_cpulist(want_list)
+    seen = {}
+
+    def worker():                                   # a fresh thread: binding it must not touch the test runner's own mask
+        seen["before"] = os.sched_getaffinity(0)
+        seen["n"] = L.mi_blur_bind_thread_to_device(0)
+        seen["after"] = os.sched_getaffinity(0)
+
+    t = threading.Thread(target=worker)
+    t.start(); t.join()
+    assert seen["after"] == (seen["before"] & local) and seen["n"] == len(seen["after"]) > 0
+    buf = L.mi_blur_host_alloc_on(0, 1 << 20)
+    assert buf
+    L.mi_blur_host_free(buf)
+    banner = f"GPU 0 host placement: feeder + batch-building threads and pinned buffers on CPUs {want_list} (NUMA node {want_node})"
+    for cmd in ([het, "gpu", "1.0", "35", "--size", "256x256", "--images", "700"], [het, "both", "0.7", "35", "--size", "256x256", "--images", "700"],
+                [het, "gpu", "1.0", "35", "--size", "256x256", "--images", "5000", "--resident"], [spl, "0.837", "35", "--size", "320x240", "--images", "140"]):
+        r = run(cmd, tmp_path)
+        assert r.returncode == 0 and banner in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([het, "gpu", "1.0", "35", "--size", "256x256", "--images", "700"], cwd=tmp_path, capture_output=True, text=True,
+                       timeout=600, env=dict(os.environ, MI_BLUR_NO_AFFINITY="1"))
+    assert r.returncode == 0 and "GPU 0 host placement: not pinned (MI_BLUR_NO_AFFINITY set)" in r.stdout, r.stdout
 
 
 @pytest.mark.gpu

@@ -753,6 +753,49 @@ def test_layout_repack_matches_reference_loops(pkg, L, O, torch_cuda, c):
     assert L.mi_blur_interleaved_to_planar(buf_p.data_ptr(), buf_i.data_ptr(), 0, h, c, n, None) == pkg.ERR_INVALID
 
 
+@pytest.mark.parametrize("radius", [1, 2])
+def test_submit_planar_frames(pkg, L, O, torch_cuda, radius):
+    """mi_blur_submit_planar: frames arrive PLANAR (CImg storage, heterogeneous_blur.c:106-124); the interleave
+    (:125-134) and the way back (split_image_blur.c:40-56) are GPU kernels inside the submit.  Pinned caller memory is read
+    / written in place by the repack kernels, pageable memory goes through the slot's staging; interleaved and planar
+    output; vector and byte repack paths (plane % 16), aligned and ragged blur shapes, several batches in flight."""
+    for (n, h, w, c) in [(35, 256, 256, 3), (6, 167, 250, 3), (9, 48, 64, 1), (5, 33, 50, 4), (3, 240, 320, 2)]:
+        inter = O.lcg_stream(n, h, w, c, first_index=77)
+        planar = np.ascontiguousarray(inter.transpose(0, 3, 1, 2))
+        want_i = want_batch(O, inter, radius)
+        want_p = np.ascontiguousarray(want_i.transpose(0, 3, 1, 2))
+        nbytes = inter.size
+        for pinned in (True, False):
+            for planar_out in (False, True):
+                with pkg.Context(0, w, h, c, radius, max_batch=n, n_slots=2) as ctx:
+                    rounds = 3                                          # more submits than slots: slot reuse + wait_oldest
+                    if pinned:
+                        pin = [L.mi_blur_host_alloc(nbytes) for _ in range(rounds)]
+                        pout = [L.mi_blur_host_alloc(nbytes) for _ in range(rounds)]
+                        for p_ in pin:
+                            C.memmove(p_, planar.ctypes.data, nbytes)
+                        for p_ in pout:
+                            C.memset(p_, 0xA5, nbytes)
+                        for k in range(rounds):
+                            ctx.submit_planar(pin[k], pout[k], n, planar_out)
+                        tm = ctx.sync()
+                        outs = [np.frombuffer(C.string_at(p_, nbytes), np.uint8) for p_ in pout]
+                        for p_ in pin + pout:
+                            L.mi_blur_host_free(p_)
+                    else:
+                        outs = [np.full(nbytes, 0xA5, np.uint8) for _ in range(rounds)]
+                        for k in range(rounds):
+                            ctx.submit_planar(planar.ctypes.data, outs[k].ctypes.data, n, planar_out)
+                        tm = ctx.sync()
+                    for o in outs:
+                        assert np.array_equal(o, (want_p if planar_out else want_i).reshape(-1)), (n, h, w, c, pinned, planar_out)
+                    assert tm["images"] == rounds * n and tm["h2d_ms"] > 0 and tm["kernel_ms"] > 0 and tm["d2h_ms"] > 0
+    with pkg.Context(0, 64, 64, 3, radius, max_batch=4, n_slots=1) as ctx:
+        a = np.zeros(4 * 64 * 64 * 3, np.uint8)
+        assert L.mi_blur_submit_planar(ctx.h, a.ctypes.data, a.ctypes.data, 4, 0) == pkg.ERR_INVALID
+        assert L.mi_blur_submit_planar(ctx.h, a.ctypes.data, a.ctypes.data + 1, 5, 0) == pkg.ERR_INVALID
+
+
 def test_planar_frames_blur_as_one_channel_images(pkg, L, O, torch_cuda):
     """A planar (CImg-layout) stream needs no repack to be blurred: it is a stream of n*C one-channel images.
     blur(planar as C=1) repacked == blur(interleaved), on the GPU end to end, 1080p 5x5 and 256x256 3x3."""

@@ -22,9 +22,24 @@ def main():
     n_sub = int(sys.argv[3]) if len(sys.argv) > 3 else 60
     pkg = entry.load_package()
     L = pkg.lib()
+    opts = [a.split("=") for a in sys.argv[4:]]                  # key=value pairs for mi_blur_set_option; arena=MiB is the probe's own
+    arena_mib = 0
+    for k, v in opts:
+        if k == "arena":
+            arena_mib = int(v)
+        else:
+            pkg.check(L.mi_blur_set_option(k.encode(), int(v)), k)
     w, h, c, r = 256, 256, 3, 1
     nbytes = nb * h * w * c
-    bufs = [(L.mi_blur_host_alloc(nbytes), L.mi_blur_host_alloc(nbytes)) for _ in range(ns)]
+    arena = None
+    if arena_mib:       # ONE pinned allocation of at least arena MiB, the batch buffers carved out of it at 2 MiB-aligned offsets
+        step = (nbytes + (2 << 20) - 1) // (2 << 20) * (2 << 20)
+        total = max(arena_mib << 20, 2 * ns * step + (2 << 20))
+        arena = L.mi_blur_host_alloc(total)
+        base = (arena + (2 << 20) - 1) // (2 << 20) * (2 << 20)
+        bufs = [(base + (2 * i) * step, base + (2 * i + 1) * step) for i in range(ns)]
+    else:
+        bufs = [(L.mi_blur_host_alloc(nbytes), L.mi_blur_host_alloc(nbytes)) for _ in range(ns)]
     for (pi, _po) in bufs:
         L.mi_blur_fill_synthetic(pi, w, h, c, 0, nb, 4)
     ctx = pkg.Context(0, w, h, c, r, max_batch=nb, n_slots=ns)
@@ -44,15 +59,18 @@ def main():
     tm = ctx.sync()
     dt = time.perf_counter() - t0
     calls_us = sorted(x * 1e6 for x in calls)
-    print(f"batch {nb} slots {ns}: {n_sub} submits in {dt * 1e3:.2f} ms = {dt / n_sub * 1e6:.1f} us per submit, "
+    print(f"batch {nb} slots {ns} {' '.join('='.join(o) for o in opts)}: {n_sub} submits in {dt * 1e3:.2f} ms = {dt / n_sub * 1e6:.1f} us per submit, "
           f"{n_sub * nb / dt:.0f} img/s, {n_sub * nbytes / dt / 1e9:.1f} GB/s each way; "
           f"mi_blur_submit call: median {calls_us[len(calls_us) // 2]:.1f} us, min {calls_us[0]:.1f}, max {calls_us[-1]:.1f}; "
           f"kernel bucket {tm['kernel_ms']:.2f} ms (union of dispatch intervals) = {tm['kernel_ms'] / (dt * 1e3) * 100:.0f} % of the wall clock",
           flush=True)
-    for (pi, po) in bufs:
-        L.mi_blur_host_free(pi)
-        L.mi_blur_host_free(po)
     ctx.close()
+    if arena:
+        L.mi_blur_host_free(arena)
+    else:
+        for (pi, po) in bufs:
+            L.mi_blur_host_free(pi)
+            L.mi_blur_host_free(po)
 
 
 if __name__ == "__main__":
