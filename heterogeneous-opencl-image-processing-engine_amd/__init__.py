@@ -157,6 +157,7 @@ def lib() -> C.CDLL:
         "mi_blur_cpu_run": (i, [u8p, u8p, i, i, i, i, i, i]),
         "mi_blur_fill_synthetic": (None, [u8p, i, i, i, i, i, i]),
         "mi_blur_fnv1a64": (C.c_uint64, [u8p, C.c_size_t]),
+        "mi_blur_debug_zc_trace": (i, [vp, C.POINTER(C.c_uint64), i, C.POINTER(i), C.POINTER(C.c_uint)]),
         "mi_blur_debug_xcd_times": (i, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), i]),
         "mi_blur_a1_partition": (None, [i, i, C.c_float, C.POINTER(i), C.POINTER(i)]),
         "mi_blur_shard_range": (None, [C.c_longlong, i, i, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),

@@ -310,8 +310,12 @@ __device__ __forceinline__ void store16_write_through(uint8_t *q, u32x4 v)
 
 // One workgroup's tile (tile number L of the launch).  Threads may return early; the only barrier is after staging.
 // WT: outputs are written through L2 (store16_write_through).
-template <int C, int R, int RPG, bool DMA, bool SHFL, bool RAG, bool WT = false, int X = rowpass_default<R>>
-__device__ __forceinline__ void tiled_tile(const TiledParams &p, unsigned L)
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// `after_staging` runs once the tile is in LDS (every global load AND every earlier store of this wave has been
+// acknowledged: s_waitcnt vmcnt(0) + barrier) and before this tile's own stores are issued.
+template <int C, int R, int RPG, bool DMA, bool SHFL, bool RAG, bool WT = false, int X = rowpass_default<R>, typename Hook = NoHook>
+__device__ __forceinline__ void tiled_tile(const TiledParams &p, unsigned L, Hook after_staging = Hook{})
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int t = threadIdx.x, NT = blockDim.x;
@@ -389,6 +393,7 @@ __device__ __forceinline__ void tiled_tile(const TiledParams &p, unsigned L)
         if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+    after_staging();
 
     // ---- compute: thread = (chunk column col, row group grp); RPG rows, sliding window.
     const int grp = t / nc, col = t - grp * nc;
@@ -534,6 +539,223 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(const TiledParams p, co
     if (threadIdx.x == 0) {
         if (f.release) __hip_atomic_fetch_add(&f.count[b * 8u + ((w ^ (w >> 3)) & 7u)], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         else __hip_atomic_fetch_add(&f.count[b * 8u + ((w ^ (w >> 3)) & 7u)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// Zero-copy batch server (see blur_launch.h): batch after batch of pinned host frames through ONE dispatch.
+//
+// Tiles are handed out by ONE ticket counter that runs through the batches (global tile g belongs to the batch whose
+// [tile_first, tile_first + n_tiles) holds it): a worker that finishes early simply draws the next ticket, also across
+// a batch boundary.  Over the host link a tile takes anywhere between 10 and 100 us depending on what is queued in
+// front of its reads, so a fixed share of tiles per workgroup (the per-batch launch: tile L to workgroup L mod n) leaves
+// every batch waiting for its unluckiest workgroup — that, not the dispatch itself, is what a batch boundary costs
+// (profiles/r03_e2e_timeline.md).
+// ----------------------------------------------------------------------------------
+static_assert(sizeof(TiledParams) <= ZC_PARAM_WORDS * 4 && sizeof(TiledParams) % 4 == 0, "TiledParams must fit a ZcBatch");
+static_assert(sizeof(ZcBatch) / 4 <= 64, "the poller copies a descriptor with one wave-instruction");
+
+template <int C, int R, int RPG>
+__global__ __launch_bounds__(256) void blur_server_kernel(ZcHostCtl *ctl, ZcDevCtl *dev, unsigned seq, unsigned budget, unsigned idle_ticks,
+                                                          unsigned long long *trace)
+{
+    const unsigned NW = gridDim.x - 1;
+    // where the previous server stopped (its dispatch is complete: same stream).  This server's poller writes the OTHER words.
+    const unsigned first = dev->next[seq & 1u];
+
+    if (blockIdx.x == NW) {
+        // ---- poller: one wave.  Host `tail` -> descriptors copied to device memory -> `avail`; tiles_done -> host `done`.
+        // Every exit path tells the workers where the server stops, and it leaves only when every batch it took is signalled.
+        const unsigned lane = threadIdx.x;
+        if (lane >= 64) return;
+        __shared__ unsigned s_ntiles[ZC_RING];
+        unsigned g = dev->gnext[seq & 1u];                                   // global tile number of batch `first`
+        if (lane == 0) {
+            __hip_atomic_store(&dev->ticket, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&dev->start_seq, seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        unsigned k = first, c = first;                                       // published to the workers / signalled to the host
+        const unsigned limit = first + budget;
+        bool stopping = false;
+        unsigned long long t_idle = wall_clock64();
+        for (;;) {
+            if (!stopping) {
+                unsigned tail = 0;
+                if (lane == 0) tail = __hip_atomic_load(&ctl->tail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                tail = __builtin_amdgcn_readfirstlane(tail);
+                const unsigned target = (int)(tail - limit) > 0 ? limit : tail;
+                const bool progressed = (int)(target - k) > 0;
+                while ((int)(target - k) > 0) {
+                    const unsigned slot = k % ZC_RING;
+                    unsigned word = 0;
+                    if (lane < sizeof(ZcBatch) / 4) {
+                        word = __hip_atomic_load(reinterpret_cast<unsigned *>(&ctl->batch[slot]) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store(reinterpret_cast<unsigned *>(&dev->batch[slot]) + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    const unsigned nt = __builtin_amdgcn_readlane(word, ZC_PARAM_WORDS + 1);     // ZcBatch::n_tiles
+                    if (lane == 0) {
+                        s_ntiles[slot] = nt;
+                        __hip_atomic_store(&ctl->t_begin[slot], wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    g += nt;
+                    k++;
+                }
+                if (progressed) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every lane's descriptor words are written
+                    if (lane == 0) __hip_atomic_store(&dev->avail, k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    t_idle = wall_clock64();
+                }
+                unsigned quit = 0;
+                if (lane == 0) quit = __hip_atomic_load(&ctl->quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                quit = __builtin_amdgcn_readfirstlane(quit);
+                if (k == limit || quit || (c == k && wall_clock64() - t_idle > (unsigned long long)idle_ticks)) {
+                    stopping = true;                                         // budget spent / told to leave / nothing to do for a while
+                    if (lane == 0) {
+                        dev->next[(seq + 1u) & 1u] = k;                      // read by the next server (after this dispatch has ended)
+                        dev->gnext[(seq + 1u) & 1u] = g;
+                        __hip_atomic_store(&dev->stop_at, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&dev->stop_tile, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&dev->stop_seq, seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            // batches complete in order: every tile of batch c has counted itself (after its stores were acknowledged)
+            while ((int)(k - c) > 0) {
+                const unsigned slot = c % ZC_RING;
+                unsigned d = 0;
+                if (lane == 0) d = __hip_atomic_load(&dev->tiles_done[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                d = __builtin_amdgcn_readfirstlane(d);
+                if (d != s_ntiles[slot]) break;
+                if (lane == 0) {
+                    __hip_atomic_store(&dev->tiles_done[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the ring slot comes round again
+                    __hip_atomic_store(&ctl->t_end[slot], wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(&ctl->done[slot], c + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                c++;
+                t_idle = wall_clock64();
+            }
+            if (stopping && c == k) break;
+            if (wall_clock64() - t_idle > ZC_HARD_TICKS) {                   // tiles that never complete: give up loudly rather than spin
+                if (lane == 0) {
+                    __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (!stopping) {
+                        dev->next[(seq + 1u) & 1u] = k; dev->gnext[(seq + 1u) & 1u] = g;
+                        __hip_atomic_store(&dev->stop_at, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&dev->stop_seq, seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (lane == 0) __hip_atomic_store(&ctl->servers_done, seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+
+    // ---- workers
+    __shared__ unsigned s_words[sizeof(ZcBatch) / 4];
+    const unsigned w = blockIdx.x;
+    __shared__ unsigned s_ctl[4];                       // [0] go / stop, [1] first ticket, [2], [3] next ticket of even / odd tiles
+    if (threadIdx.x == 0) {
+        const unsigned long long t_gate = wall_clock64();
+        unsigned ok = 1u;
+        while (__hip_atomic_load(&dev->start_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq + 1u) {
+            if (wall_clock64() - t_gate > ZC_HARD_TICKS) { ok = 0u; __hip_atomic_store(&ctl->error, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        s_ctl[0] = ok;
+    }
+    __syncthreads();
+    if (!s_ctl[0]) return;
+    __syncthreads();
+    union { TiledParams p; unsigned words[sizeof(TiledParams) / 4]; } u;
+    unsigned k = first, have = 0u, tile_first = 0u, n_tiles = 0u;
+    unsigned pending = ~0u;                             // ring slot of the tile whose stores may still be in flight
+    // count a finished tile into its batch: called when its stores have been acknowledged
+    auto count_pending = [&]() {
+        if (pending != ~0u && threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                    // system scope: the tile's bytes before the count
+            __hip_atomic_fetch_add(&dev->tiles_done[pending], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        pending = ~0u;
+    };
+    auto flush_pending = [&]() {                        // no next tile to hide behind: wait for the stores here
+        if (pending != ~0u) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            count_pending();
+        }
+    };
+    if (threadIdx.x == 0) s_ctl[1] = __hip_atomic_fetch_add(&dev->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    unsigned t = s_ctl[1];
+    unsigned long long *tr = nullptr;
+    for (unsigned it = 0;; it++) {
+        // ---- the batch ticket t belongs to
+        for (;;) {
+            if (!have) {
+                // is batch k published?  0 = the server stops before it, 1 = yes, 2 = not yet (and not stopping)
+                auto look = [&]() -> unsigned {
+                    const unsigned a = __hip_atomic_load(&dev->avail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((int)(a - k) > 0) return 1u;
+                    if (__hip_atomic_load(&dev->stop_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == seq + 1u &&
+                        (int)(__hip_atomic_load(&dev->stop_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - k) <= 0) return 0u;
+                    return 2u;
+                };
+                if (threadIdx.x == 0) s_ctl[0] = look();
+                __syncthreads();
+                unsigned go = s_ctl[0];
+                __syncthreads();
+                if (go != 1u) {
+                    flush_pending();                 // waiting or leaving: do not sit on a finished tile meanwhile
+                    if (go == 2u) {
+                        if (threadIdx.x == 0) {
+                            unsigned g2;
+                            const unsigned long long t_w = wall_clock64();
+                            while ((g2 = look()) == 2u) {
+                                if (wall_clock64() - t_w > ZC_HARD_TICKS) { g2 = 0u; __hip_atomic_store(&ctl->error, 3u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                                __builtin_amdgcn_s_sleep(4);
+                            }
+                            s_ctl[0] = g2;
+                        }
+                        __syncthreads();
+                        go = s_ctl[0];
+                        __syncthreads();
+                    }
+                    if (!go) return;                 // the server stops before batch k
+                }
+                // descriptor of batch k: the poller copied it into device memory before it released `avail`
+                if (threadIdx.x < sizeof(ZcBatch) / 4)
+                    s_words[threadIdx.x] = __hip_atomic_load(reinterpret_cast<unsigned *>(&dev->batch[k % ZC_RING]) + threadIdx.x, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+#pragma unroll
+                for (unsigned i = 0; i < sizeof(TiledParams) / 4; i++) u.words[i] = __builtin_amdgcn_readfirstlane(s_words[i]);   // wave-uniform: SGPRs
+                tile_first = __builtin_amdgcn_readfirstlane(s_words[ZC_PARAM_WORDS]);
+                n_tiles = __builtin_amdgcn_readfirstlane(s_words[ZC_PARAM_WORDS + 1]);
+                have = 1u;
+                // the host wrote the frames before it published `tail`; the poller acquired that at system scope and released
+                // `avail` at agent scope: take the same view before reading host memory
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+                __syncthreads();
+            }
+            if ((int)(t - (tile_first + n_tiles)) >= 0) { k++; have = 0u; continue; }     // the ticket lies beyond this batch
+            break;
+        }
+        // diagnostics (trace != nullptr): per worker and batch (the context's first ZC_TRACE_BATCHES only) — first tile taken at,
+        // tiles taken, device-clock ticks inside tiles, last tile finished at
+        tr = (trace && k < ZC_TRACE_BATCHES && threadIdx.x == 0) ? trace + ((size_t)k * NW + w) * 5u : nullptr;
+        if (tr) { if (tr[0] == 0) tr[0] = wall_clock64(); tr[1] += 1; }
+        // ---- draw the next ticket now (its round trip hides behind the tile), then the tile
+        // (two LDS words, taken in turn: a wave that is already drawing for the next tile must not overwrite the word a slower
+        // wave of the block has not read yet — the barriers of one whole tile lie between two writes of the same word)
+        if (threadIdx.x == 0) s_ctl[2u + (it & 1u)] = __hip_atomic_fetch_add(&dev->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t_a = trace ? wall_clock64() : 0ull;
+        tiled_tile<C, R, RPG, true, false, false, false, rowpass_default<R>>(u.p, t - tile_first, count_pending);
+        pending = k % ZC_RING;
+        __syncthreads();                              // the next tile is staged into the same LDS; the next ticket is in LDS
+        if (tr) { tr[2] += wall_clock64() - t_a; tr[3] = wall_clock64(); }
+        t = s_ctl[2u + (it & 1u)];
     }
 }
 
@@ -828,7 +1050,7 @@ static std::mutex &tunables_mutex() { static std::mutex m; return m; }
 static Tunables &tunables_storage()
 {
     static Tunables t = [] {
-        Tunables v{1, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0, 4, 24, 1, 1, 8, 0, 8, 1};  // rpg 0 / stream_bh 0 = choose per launch
+        Tunables v{1, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0, 4, 24, 1, 1, 8, 0, 8, 1, 48, 300, 256, 0, 1};  // rpg 0 / stream_bh 0 = choose per launch
         if (const char *e = getenv("MI_BLUR_STAGE")) v.stage_dma = strcmp(e, "reg") != 0;
         if (const char *e = getenv("MI_BLUR_RPG")) { const int r = atoi(e); v.rpg = (r == 4 || r == 8 || r == 16) ? r : 0; }
         if (const char *e = getenv("MI_BLUR_XCD")) v.xcd_remap = atoi(e) != 0;
@@ -963,23 +1185,24 @@ static int launch_fused_r(const LaunchDesc &d, const TiledParams &p, const Fused
     return MI_BLUR_ERR_INVALID;
 }
 
-static int launch_tiled(const LaunchDesc &d, const Tunables &tun, bool ragged = false, const FusedDesc *fused = nullptr)
+// Tile geometry of one launch of the tiled kernel family: fills p and returns the output rows per thread it chose.
+// rpg_forced > 0 pins that choice (the zero-copy batch server runs one geometry for every batch).
+static int tiled_geometry(const LaunchDesc &d, const Tunables &tun, bool ragged, bool fused, int rpg_forced, TiledParams &p,
+                          unsigned *block_threads, size_t *lds_bytes)
 {
-    if (!(fused && fused->geometry_only))
-        g_last_kernel = fused ? "blur_fused_kernel" : (d.max_blocks > 0 && !ragged ? "blur_tiled_loop_kernel" : "blur_tiled_kernel");
     const int R = d.radius;
     const int pitch = d.width * d.channels, cpr = (pitch + 15) / 16, rows = d.y1 - d.y0;   // ragged: last chunk partial
     // Output rows per thread.  8 amortises the 2R priming rows of the sliding window best when the grid is
     // large; small and mid-size grids (a batch of 35 256x256 images is ~840 waves at 8 rows) finish sooner
     // with 4 — more, shorter waves per CU (measured: 6.2 vs 7.4 us at batch 35, equal by ~20k waves).
-    int rpg = tun.rpg;
+    int rpg = rpg_forced > 0 ? rpg_forced : tun.rpg;
     if (rpg == 0) {
         const long long waves8 = (long long)d.n_images * rows * cpr / (8 * 64);
         rpg = waves8 < 16384 ? 4 : 8;
     }
     if ((ragged || fused) && rpg == 16) rpg = 8;
 
-    TiledParams p{};
+    p = TiledParams{};
     p.in = d.in; p.out = d.out;
     p.in_stride = d.in_stride ? d.in_stride : (long long)d.band_rows * pitch;
     p.out_stride = d.out_stride ? d.out_stride : (long long)rows * pitch;
@@ -1018,9 +1241,23 @@ static int launch_tiled(const LaunchDesc &d, const Tunables &tun, bool ragged = 
     p.debug_copy = tun.debug_copy;
     p.xcd_times = tun.debug_xcd_times ? debug_xcd_buffer() : nullptr;
     p.tail = pitch % 16 ? pitch % 16 : 16;
+    *block_threads = (unsigned)((p.ncols * p.ngroups + 63) / 64 * 64);
+    *lds_bytes = (size_t)(p.TH + 2 * R) * (p.ncols + 2) * 16;
+    return rpg;
+}
 
-    const dim3 grid((unsigned)nblocks), block((unsigned)((p.ncols * p.ngroups + 63) / 64 * 64));
-    const size_t lds = (size_t)(p.TH + 2 * R) * (p.ncols + 2) * 16;
+static int launch_tiled(const LaunchDesc &d, const Tunables &tun, bool ragged = false, const FusedDesc *fused = nullptr)
+{
+    if (!(fused && fused->geometry_only))
+        g_last_kernel = fused ? "blur_fused_kernel" : (d.max_blocks > 0 && !ragged ? "blur_tiled_loop_kernel" : "blur_tiled_kernel");
+    const int R = d.radius;
+    TiledParams p{};
+    unsigned threads = 0;
+    size_t lds = 0;
+    const int rpg = tiled_geometry(d, tun, ragged, fused != nullptr, 0, p, &threads, &lds);
+    if (rpg < 0) return rpg;
+    const long long nblocks = p.nblocks;
+    const dim3 grid((unsigned)nblocks), block(threads);
     if (fused) {
         FusedParams f{};
         f.count = fused->count;
@@ -1038,6 +1275,51 @@ static int launch_tiled(const LaunchDesc &d, const Tunables &tun, bool ragged = 
     }
     return R == 1 ? launch_tiled_r<1>(d, p, grid, block, lds, rpg, tun.stage_dma != 0, ragged, tun.row_shuffle != 0, tun.experiment)
                   : launch_tiled_r<2>(d, p, grid, block, lds, rpg, tun.stage_dma != 0, ragged, tun.row_shuffle != 0, tun.experiment);
+}
+
+// ---- zero-copy batch server: host side of the launch interface (blur_launch.h)
+int zc_fill_batch(const LaunchDesc &d, ZcGeometry *geo, ZcBatch *b, unsigned *n_tiles)
+{
+    if (!geo || !b || !d.in || !d.out || d.n_images <= 0) return MI_BLUR_ERR_INVALID;
+    if (!tiled_eligible(d.in, d.out, d.width, d.channels)) return MI_BLUR_ERR_UNSUPPORTED;
+    if ((d.in_stride % 16) || (d.out_stride % 16)) return MI_BLUR_ERR_UNSUPPORTED;
+    Tunables tun = tunables();
+    tun.debug_copy = 0; tun.debug_xcd_times = 0; tun.xcd_remap = 0;      // tiles are dealt to the workers by the server itself
+    TiledParams p{};
+    unsigned threads = 0;
+    size_t lds = 0;
+    const int rpg = tiled_geometry(d, tun, false, false, 4, p, &threads, &lds);
+    if (rpg < 0) return rpg;
+    if (geo->threads == 0) { geo->threads = threads; geo->lds = lds; geo->rpg = rpg; geo->channels = d.channels; geo->radius = d.radius; }
+    else if (geo->threads != threads || geo->lds != lds || geo->rpg != rpg || geo->channels != d.channels || geo->radius != d.radius)
+        return MI_BLUR_ERR_UNSUPPORTED;                                      // another tile shape than the running server's
+    memset(b->params, 0, sizeof b->params);
+    memcpy(b->params, &p, sizeof p);
+    if (n_tiles) *n_tiles = p.nblocks;
+    return MI_BLUR_OK;
+}
+
+int zc_launch_server(const ZcGeometry &geo, ZcHostCtl *ctl, ZcDevCtl *dev, unsigned seq, unsigned n_workers, unsigned budget,
+                     unsigned idle_ticks, hipStream_t stream, unsigned long long *trace)
+{
+    if (!ctl || !dev || n_workers == 0 || geo.threads == 0 || geo.rpg != 4) return MI_BLUR_ERR_INVALID;
+    g_last_kernel = "blur_server_kernel";
+    const dim3 grid(n_workers + 1), block(geo.threads);
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, grid, block, geo.lds, stream, ctl, dev, seq, budget, idle_ticks, trace);
+        return hip_status(hipGetLastError());
+    };
+    switch (geo.channels * 10 + geo.radius) {
+    case 11: return go(blur_server_kernel<1, 1, 4>);
+    case 12: return go(blur_server_kernel<1, 2, 4>);
+    case 21: return go(blur_server_kernel<2, 1, 4>);
+    case 22: return go(blur_server_kernel<2, 2, 4>);
+    case 31: return go(blur_server_kernel<3, 1, 4>);
+    case 32: return go(blur_server_kernel<3, 2, 4>);
+    case 41: return go(blur_server_kernel<4, 1, 4>);
+    case 42: return go(blur_server_kernel<4, 2, 4>);
+    }
+    return MI_BLUR_ERR_INVALID;
 }
 
 int launch_fused(const LaunchDesc &d, const FusedDesc &f)

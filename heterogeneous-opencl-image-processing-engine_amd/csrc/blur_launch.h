@@ -44,6 +44,55 @@ int launch_fused(const LaunchDesc &d, const FusedDesc &f);
 int launch_planar_to_interleaved(const uint8_t *src, uint8_t *dst, int width, int height, int channels, int n_images, hipStream_t s);
 int launch_interleaved_to_planar(const uint8_t *src, uint8_t *dst, int width, int height, int channels, int n_images, hipStream_t s);
 
+// ----------------------------------------------------------------------------------------------------------------
+// Zero-copy batch server (blur_server_kernel): ONE long-lived dispatch takes batch after batch of pinned host frames from a
+// ring of descriptors the host fills, so consecutive batches of a host-fed stream flow through the same workgroups with
+// no dispatch boundary between them (a per-batch launch costs the host link ~45 us of a ~200 us batch, profiles/r03_e2e_timeline.md).
+//   host -> device: ZcHostCtl::batch[k % ZC_RING] (the tile parameters of batch k), then tail = k + 1
+//   device -> host: done[k % ZC_RING] = k + 1 once every output byte of batch k is in host memory
+// The grid is n_workers + 1 workgroups: the last one is the POLLER (reads `tail` over the host link, republishes it in
+// device memory, decides when the server ends), the others walk the tiles.  A server ALWAYS ends: after `budget` batches,
+// after idle_ticks (100 MHz) without a new batch, or when the host sets `quit`; its workers leave once the poller has said
+// where the server stops.  The host keeps the next server queued behind the running one on the same stream.
+// ----------------------------------------------------------------------------------------------------------------
+constexpr unsigned ZC_RING = 64;
+constexpr unsigned ZC_PARAM_WORDS = 32;
+constexpr unsigned ZC_TRACE_BATCHES = 512;
+constexpr unsigned long long ZC_HARD_TICKS = 1000000000ull;   // 10 s of the 100 MHz device clock: no wait inside a server outlasts this   // diagnostics: the trace keeps the stamps of the last this-many batches
+struct ZcBatch {
+    unsigned params[ZC_PARAM_WORDS];   // TiledParams of the batch, as words
+    unsigned tile_first;               // global number of the batch's first tile (tiles are numbered through the batches, mod 2^32)
+    unsigned n_tiles;
+    unsigned pad[6];
+};
+struct ZcHostCtl {                     // pinned, device-visible host memory
+    unsigned tail;                     // host -> device: descriptors published so far
+    unsigned quit;                     // host -> device: leave at the next poll
+    unsigned servers_done;             // device -> host: servers that have signalled every batch they took and left
+    unsigned error;                    // device -> host: a server's wait ran into its hard limit (ZC_HARD_TICKS) — should never happen
+    unsigned pad0[12];
+    unsigned done[ZC_RING];            // device -> host: done[k % ZC_RING] = k + 1
+    unsigned long long t_begin[ZC_RING], t_end[ZC_RING];   // device clock (100 MHz ticks): batch k taken up / complete
+    ZcBatch batch[ZC_RING];
+};
+struct ZcDevCtl {                      // device memory, zeroed when the server state is created
+    unsigned next[2];                  // server `seq` starts at batch next[seq & 1] and leaves next[(seq + 1) & 1]
+    unsigned gnext[2];                 // ... and at global tile gnext[seq & 1]
+    unsigned start_seq;                // poller -> workers: server (start_seq - 1) has set the ticket counter
+    unsigned avail;                    // poller -> workers: batches [.., avail) are published (descriptors in `batch`)
+    unsigned stop_seq, stop_at, stop_tile;   // poller -> workers: server (stop_seq - 1) ends before batch stop_at / tile stop_tile
+    unsigned ticket;                   // next global tile to hand out
+    unsigned pad[6];
+    unsigned tiles_done[ZC_RING];      // tiles of the batch in this ring slot whose output is in host memory
+    ZcBatch batch[ZC_RING];            // device copies of the descriptors
+};
+struct ZcGeometry { unsigned threads; size_t lds; int rpg; int channels, radius; };
+// Tile parameters of one batch (d.in/d.out = DEVICE addresses of the pinned buffers) in the server's geometry; *geo is
+// filled on the first call (geo->threads == 0) and must match on later ones (MI_BLUR_ERR_UNSUPPORTED otherwise).
+int zc_fill_batch(const LaunchDesc &d, ZcGeometry *geo, ZcBatch *b, unsigned *n_tiles);
+int zc_launch_server(const ZcGeometry &geo, ZcHostCtl *ctl, ZcDevCtl *dev, unsigned seq, unsigned n_workers, unsigned budget,
+                     unsigned idle_ticks, hipStream_t stream, unsigned long long *trace = nullptr);
+
 // Name of the kernel the calling thread's most recent launch() / launch_fused() chose ("" before the first).
 const char *last_kernel();
 
@@ -68,6 +117,12 @@ struct Tunables {
     int direct_bh;       // direct variant: output rows per lane (8; 4 | 12 | 16 instantiated for C = 3 only, A/B runs)
     int debug_xcd_times; // diagnostics: the tiled kernel's workgroups leave start/end times per XCD (mi_blur_debug_xcd_times)
     int fused_window;    // fused stream: batches per window of its blockIdx -> tile map (8: one whole batch per XCD per window)
+    int zero_copy_server;  // zero-copy submits of aligned shapes go through the batch server (one long-lived dispatch per stream of
+                           // batches, blur_server_kernel) instead of one launch per batch: 1 (default) | 0
+    int zero_copy_workers; // batch server: worker workgroups (default 48: 40-64 measured best, profiles/r03_e2e_timeline.md)
+    int zero_copy_idle_us; // batch server: leaves after this long without a new batch (default 300)
+    int zero_copy_budget;  // batch server: leaves after this many batches, the queued next one carries on (default 256)
+    int zero_copy_trace;   // diagnostics: the batch server's workers stamp their phases per batch (mi_blur_debug_zc_trace)
     int zero_copy_events; // zero-copy submits: 1 = the dispatch carries start/stop timestamp events (kernel bucket + completion),
                          // 0 = plain launch, completion by stream synchronise (timing experiment: no kernel bucket)
 };

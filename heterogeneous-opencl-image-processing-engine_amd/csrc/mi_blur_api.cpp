@@ -100,6 +100,11 @@ extern "C" int mi_blur_set_option(const char *key, int value)
     else if (!strcmp(key, "fused_window")) { if (value < 1 || value > 4096) return MI_BLUR_ERR_INVALID; t.fused_window = value; }
     else if (!strcmp(key, "debug_xcd_times")) t.debug_xcd_times = value != 0;
     else if (!strcmp(key, "zero_copy_events")) t.zero_copy_events = value != 0;
+    else if (!strcmp(key, "zero_copy_server")) t.zero_copy_server = value != 0;
+    else if (!strcmp(key, "zero_copy_trace")) t.zero_copy_trace = value != 0;
+    else if (!strcmp(key, "zero_copy_workers")) { if (value < 1 || value > 2048) return MI_BLUR_ERR_INVALID; t.zero_copy_workers = value; }
+    else if (!strcmp(key, "zero_copy_idle_us")) { if (value < 10 || value > 100000) return MI_BLUR_ERR_INVALID; t.zero_copy_idle_us = value; }
+    else if (!strcmp(key, "zero_copy_budget")) { if (value < 1 || value > (1 << 20)) return MI_BLUR_ERR_INVALID; t.zero_copy_budget = value; }
     else if (!strcmp(key, "xcd_run")) { if (value < 0 || value > (1 << 20)) return MI_BLUR_ERR_INVALID; t.xcd_run = value; }
     else return MI_BLUR_ERR_INVALID;
     set_tunables(t);
@@ -171,9 +176,24 @@ struct Slot {
     bool zero_copy = false;                               // in flight on the context's zero-copy stream
     bool zc_plain = false;                                // ... as a plain launch without events (experiment)
     hipStream_t zc_stream = nullptr;
+    bool zc_server = false;                               // ... as batch zc_index of the context's batch server
+    unsigned zc_index = 0;
 };
 
 struct TimedLaunch { hipEvent_t s, e; };
+
+// Host side of the zero-copy batch server (blur_launch.h): the descriptor ring in pinned memory, the device-side
+// hand-off words, the stream the servers queue on, and what has been published / launched so far.
+struct ZcServer {
+    ZcHostCtl *ctl = nullptr, *ctl_dev = nullptr;          // pinned host memory and its device address
+    ZcDevCtl *dev = nullptr;
+    hipStream_t stream = nullptr;
+    ZcGeometry geo{};
+    unsigned head = 0, launched = 0, tile_base = 0;
+    unsigned n_workers = 96, budget = 256, idle_ticks = 30000;
+    unsigned long long covered = 0;                      // kernel bucket: the union of [t_begin, t_end] so far reaches this tick
+    unsigned long long *trace = nullptr;                 // diagnostics ("zero_copy_trace"): device buffer of per-worker phase stamps
+};
 
 struct CpuJob {
     std::thread th;
@@ -210,6 +230,7 @@ struct mi_blur_ctx {
     int fused_n = 0, fused_batch = 0;                            // its (n_images, batch): same again = counters keep counting up
     unsigned fused_passes = 0;                                   // passes accumulated in the counters since they were zeroed
     hipStream_t fused_poll = nullptr;
+    ZcServer *zc = nullptr;                                      // batch server, made on the first submit that can use it
     // CPU device
     std::vector<CpuJob *> cpu_jobs;
     bool is_cpu() const { return device == MI_BLUR_DEVICE_CPU; }
@@ -404,6 +425,30 @@ static int finish_slot(mi_blur_ctx *c, Slot &s)
 {
     if (!s.busy) return MI_BLUR_OK;
     float ms = 0.f;
+    if (s.zero_copy && s.zc_server) {                            // batch zc_index of the batch server: wait for its done word
+        ZcServer &z = *c->zc;
+        const unsigned slot = s.zc_index % ZC_RING, want = s.zc_index + 1u;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0; __atomic_load_n(&z.ctl->done[slot], __ATOMIC_ACQUIRE) != want; spins++) {
+            if (spins < 4096) { __builtin_ia32_pause(); continue; }
+            if (__atomic_load_n(&z.ctl->error, __ATOMIC_ACQUIRE)) return MI_BLUR_ERR_STATE;   // a server gave up on a wait (see blur_server_kernel)
+            std::this_thread::yield();
+            if ((spins & 1023u) == 0) {                          // a faulted device never writes the word: ask the stream now and then
+                const hipError_t q = hipStreamQuery(z.stream);
+                if (q != hipSuccess && q != hipErrorNotReady) { (void)hipGetLastError(); return MI_BLUR_ERR_HIP_BASE - (int)q; }
+                (void)hipGetLastError();
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) return MI_BLUR_ERR_STATE;
+            }
+        }
+        const unsigned long long b = __atomic_load_n(&z.ctl->t_begin[slot], __ATOMIC_RELAXED), e = __atomic_load_n(&z.ctl->t_end[slot], __ATOMIC_RELAXED);
+        if (e >= b) {                                            // kernel bucket = union of the batches' [begin, end] (100 MHz device clock)
+            const unsigned long long from = std::max(b, z.covered);
+            if (e > from) c->tm.kernel_ms += (double)(e - from) / 1e5;
+            z.covered = std::max(z.covered, e);
+        }
+        s.zero_copy = false; s.zc_server = false; s.busy = false;
+        return MI_BLUR_OK;
+    }
     if (s.zero_copy) {                                           // launched on one of the context's zero-copy streams
         if (s.zc_plain) {                                        // experiment: no events on the dispatch
             HIP_TRY(hipStreamSynchronize(s.zc_stream));
@@ -503,6 +548,20 @@ extern "C" void mi_blur_destroy(mi_blur_ctx *c)
     if (!c->is_cpu()) {
         (void)hipSetDevice(c->device);
         for (auto &s : c->slots) { if (s.stream) (void)hipStreamSynchronize(s.stream); }
+        if (c->zc) {                                             // tell the servers to leave, wait for them, release
+            ZcServer &z = *c->zc;
+            if (z.ctl) __atomic_store_n(&z.ctl->quit, 1u, __ATOMIC_RELEASE);
+            if (getenv("MI_BLUR_DEBUG_SERVER"))
+                fprintf(stderr, "[mi_blur] destroy: server state head %u launched %u servers_done %u tail %u; stream query %d\n", z.head, z.launched,
+                        z.ctl ? z.ctl->servers_done : 0u, z.ctl ? z.ctl->tail : 0u, z.stream ? (int)hipStreamQuery(z.stream) : -1);
+            if (z.stream) { (void)hipStreamSynchronize(z.stream); (void)hipStreamDestroy(z.stream); }
+            if (getenv("MI_BLUR_DEBUG_SERVER")) fprintf(stderr, "[mi_blur] destroy: servers gone\n");
+            if (z.dev) (void)hipFree(z.dev);
+            if (z.trace) (void)hipFree(z.trace);
+            if (z.ctl) (void)hipHostFree(z.ctl);
+            delete c->zc;
+            c->zc = nullptr;
+        }
         for (auto &s : c->slots) free_slot(s);
         for (auto &t : c->ev_pool) { (void)hipEventDestroy(t.s); (void)hipEventDestroy(t.e); }
         if (c->zc_ref) (void)hipEventDestroy(c->zc_ref);
@@ -514,6 +573,69 @@ extern "C" void mi_blur_destroy(mi_blur_ctx *c)
         (void)hipGetLastError();
     }
     delete c;
+}
+
+// Hand one zero-copy batch to the context's batch server.  MI_BLUR_ERR_UNSUPPORTED = "not this path" (another tile shape
+// than the running server's): the caller launches the batch the classic way.
+static int zc_server_submit(mi_blur_ctx *c, Slot &s, const LaunchDesc &d, const Tunables &tun)
+{
+    if (c->slots.size() > ZC_RING) return MI_BLUR_ERR_UNSUPPORTED;
+    if (!c->zc) {
+        ZcServer *z = new (std::nothrow) ZcServer;
+        if (!z) return MI_BLUR_ERR_NOMEM;
+        // The server stream is non-blocking, i.e. NOT ordered behind the NULL stream, and hipMemset of device memory may
+        // return before the fill has run: the zero-fills go on the server stream itself, in front of the first server.
+        hipError_t e = hipHostMalloc((void **)&z->ctl, sizeof(ZcHostCtl), hipHostMallocDefault);
+        if (e == hipSuccess) { memset(z->ctl, 0, sizeof(ZcHostCtl)); e = hipHostGetDevicePointer((void **)&z->ctl_dev, z->ctl, 0); }
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&z->stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc((void **)&z->dev, sizeof(ZcDevCtl));
+        if (e == hipSuccess) e = hipMemsetAsync(z->dev, 0, sizeof(ZcDevCtl), z->stream);
+        if (e == hipSuccess && tun.zero_copy_trace) {
+            const size_t tb = (size_t)ZC_TRACE_BATCHES * (size_t)tun.zero_copy_workers * 5u * sizeof(unsigned long long);
+            e = hipMalloc((void **)&z->trace, tb);
+            if (e == hipSuccess) e = hipMemsetAsync(z->trace, 0, tb, z->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(z->stream);          // once per context: the fills are done before anything is launched
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (z->stream) (void)hipStreamDestroy(z->stream);
+            if (z->dev) (void)hipFree(z->dev);
+            if (z->trace) (void)hipFree(z->trace);
+            if (z->ctl) (void)hipHostFree(z->ctl);
+            delete z;
+            return MI_BLUR_ERR_HIP_BASE - (int)e;
+        }
+        z->n_workers = (unsigned)tun.zero_copy_workers;
+        z->budget = (unsigned)tun.zero_copy_budget;
+        z->idle_ticks = (unsigned)tun.zero_copy_idle_us * 100u;      // 100 MHz device clock
+        c->zc = z;
+    }
+    ZcServer &z = *c->zc;
+    ZcBatch b{};
+    unsigned n_tiles = 0;
+    int rc = zc_fill_batch(d, &z.geo, &b, &n_tiles);
+    if (rc) return rc;
+    // A worker scans the descriptors from the batch of its last ticket to the batch of its next one, and the ticket counter
+    // can be n_workers tiles beyond the newest published batch: with batches of very few tiles that span, plus the batches
+    // the host may publish meanwhile, must stay inside the ring.  (Such batches gain nothing from the server anyway.)
+    if (n_tiles == 0 || z.n_workers / n_tiles + 2u * (unsigned)c->slots.size() + 2u > ZC_RING) return MI_BLUR_ERR_UNSUPPORTED;
+    b.tile_first = z.tile_base;                                          // tiles are numbered through the batches
+    b.n_tiles = n_tiles;
+    z.tile_base += n_tiles;
+    const unsigned k = z.head;
+    memcpy(&z.ctl->batch[k % ZC_RING], &b, sizeof b);
+    __atomic_store_n(&z.ctl->tail, k + 1u, __ATOMIC_RELEASE);           // the frames and the descriptor are written: publish
+    z.head = k + 1u;
+    // Keep TWO servers that have not said they stopped: the running one may be deciding to leave (idle, budget) just as
+    // this batch is published; the one queued behind it on the same stream then takes it.
+    const unsigned stopped = __atomic_load_n(&z.ctl->servers_done, __ATOMIC_ACQUIRE);
+    while (z.launched - stopped < 2u) {
+        rc = zc_launch_server(z.geo, z.ctl_dev, z.dev, z.launched, z.n_workers, z.budget, z.idle_ticks, z.stream, z.trace);
+        if (rc) return rc;
+        z.launched++;
+    }
+    s.zc_server = true; s.zc_index = k;
+    return MI_BLUR_OK;
 }
 
 // One batch through a slot: Write -> NDRange -> Read (heterogeneous_blur.c:520-533), but one
@@ -567,6 +689,20 @@ static int submit_common(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_o
                 d.in = zin; d.out = zout; d.width = c->W; d.band_rows = band_rows; d.channels = c->C;
                 d.radius = c->R; d.n_images = n_images; d.y0 = y0; d.y1 = y1; d.variant = MI_BLUR_VARIANT_AUTO;
                 d.in_stride = (long long)in_stride; d.out_stride = (long long)out_stride;
+                if (tunables().zero_copy_server) {
+                    rc = zc_server_submit(c, s, d, tunables());
+                    if (rc == MI_BLUR_OK) {
+                        s.zero_copy = true; s.busy = true;
+                        c->tm.bytes_h2d += in_bytes; c->tm.bytes_d2h += out_bytes;
+                        c->tm.bytes_alg += 2ull * out_bytes;
+                        c->tm.images += (uint64_t)n_images;
+                        c->tm.launches += 1;
+                        c->zero_copy_launches += 1;
+                        return MI_BLUR_OK;
+                    }
+                    if (rc != MI_BLUR_ERR_UNSUPPORTED) return rc;
+                    s.zc_server = false;
+                }
                 const bool with_events = tunables().zero_copy_events != 0;
                 d.stream = zs;
                 if (with_events) { d.start = s.ks; d.stop = s.ke; }
@@ -1005,6 +1141,26 @@ extern "C" int mi_blur_debug_xcd_times(uint64_t end_ticks[8], uint64_t begin_tic
     for (int i = 0; i < 8; i++) { if (end_ticks) end_ticks[i] = e[i]; if (begin_ticks) begin_ticks[i] = b[i]; }
     if (rearm) HIP_TRY(hipMemset(d, 0, 16 * n));
     return MI_BLUR_OK;
+}
+
+// Diagnostics (see mi_blur.h): the batch server's per-worker phase stamps of the most recent batches.
+extern "C" int mi_blur_debug_zc_trace(mi_blur_ctx *c, uint64_t *out, int max_batches, int *n_workers, unsigned *batches_published)
+{
+    if (!c || !out || max_batches <= 0) return MI_BLUR_ERR_INVALID;
+    if (c->is_cpu() || !c->zc || !c->zc->trace) return MI_BLUR_ERR_STATE;
+    ZcServer &z = *c->zc;
+    HIP_TRY(hipSetDevice(c->device));
+    const int nb = std::min<int>(max_batches, (int)ZC_TRACE_BATCHES);
+    std::vector<unsigned long long> all;
+    try { all.resize((size_t)ZC_TRACE_BATCHES * z.n_workers * 5u); } catch (...) { return MI_BLUR_ERR_NOMEM; }
+    HIP_TRY(hipMemcpy(all.data(), z.trace, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));   // (waits for idle servers to leave)
+    // the context's first nb batches (the trace covers batches 0 .. ZC_TRACE_BATCHES-1 of a context)
+    const int have = (int)std::min<unsigned>(z.head, (unsigned)nb);
+    memcpy(out, all.data(), (size_t)have * z.n_workers * 5u * sizeof(unsigned long long));
+    const int nb_out = have;
+    if (n_workers) *n_workers = (int)z.n_workers;
+    if (batches_published) *batches_published = z.head;
+    return nb_out;
 }
 
 extern "C" uint64_t mi_blur_fnv1a64(const uint8_t *host, size_t n) { return fnv1a64(host, n); }

@@ -307,6 +307,13 @@ int mi_blur_cpu_run(const uint8_t *in, uint8_t *out, int width, int height, int 
  * rearm = 1 before the launches to be examined).  Shows which XCD a launch waits for (profiles/r02_xcd_finish_times.txt). */
 int mi_blur_debug_xcd_times(uint64_t end_ticks[8], uint64_t begin_ticks[8], int rearm);
 
+/* Developer diagnostics of the zero-copy batch server (mi_blur_set_option("zero_copy_trace", 1) before the context's first
+ * zero-copy submit): per worker workgroup and batch, for the context's first 512 batches — device clock (100 MHz ticks)
+ * when it took its first tile of the batch, how many tiles it took, ticks spent inside tiles, device clock when its last
+ * tile of the batch ended, (unused).  Copies out[batch][worker][5] for the first min(max_batches, 512, published) batches
+ * and returns how many that is (negative = mi_blur_status).  profiles/r03_e2e_timeline.md is built from it. */
+int mi_blur_debug_zc_trace(mi_blur_ctx *ctx, uint64_t *out, int max_batches, int *n_workers, unsigned *batches_published);
+
 /* Synthetic stream generator shared by hosts, bench and tests. */
 void mi_blur_fill_synthetic(uint8_t *host, int width, int height, int channels,
                             int first_index, int n_images, int n_threads);

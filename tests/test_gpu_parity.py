@@ -55,6 +55,10 @@ def reset_opts(L):
     L.mi_blur_set_option(b"xcd_run", 0)
     L.mi_blur_set_option(b"prefer_direct", 1)
     L.mi_blur_set_option(b"direct_bh", 8)
+    L.mi_blur_set_option(b"zero_copy_server", 1)
+    L.mi_blur_set_option(b"zero_copy_workers", 48)
+    L.mi_blur_set_option(b"zero_copy_idle_us", 300)
+    L.mi_blur_set_option(b"zero_copy_budget", 256)
 
 
 def want_batch(O, host, radius):
@@ -408,6 +412,7 @@ def test_zero_copy_capped_grid_and_streams(pkg, L, O, torch_cuda, radius):
     nbytes = n * h * w * c
     bufs = [(L.mi_blur_host_alloc(nbytes), L.mi_blur_host_alloc(nbytes)) for _ in range(4)]
     try:
+        pkg.check(L.mi_blur_set_option(b"zero_copy_server", 0))              # this test is about the one-launch-per-batch form
         for k, (pi, _po) in enumerate(bufs):
             C.memmove(pi, host[k * n:(k + 1) * n].ctypes.data, nbytes)
         for streams, cap in ((1, 1), (4, 1), (2, 5), (4, 24), (3, 100000), (4, 0)):
@@ -430,8 +435,97 @@ def test_zero_copy_capped_grid_and_streams(pkg, L, O, torch_cuda, radius):
                     got = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(po)).reshape(n, h, w, c)
                     assert np.array_equal(got, want[k * n:(k + 1) * n]), (streams, cap, k)
     finally:
+        pkg.check(L.mi_blur_set_option(b"zero_copy_server", 1))
         pkg.check(L.mi_blur_set_option(b"zero_copy_streams", 4))
         pkg.check(L.mi_blur_set_option(b"zero_copy_blocks", 24))
+        for (pi, po) in bufs:
+            L.mi_blur_host_free(pi); L.mi_blur_host_free(po)
+
+
+@pytest.mark.parametrize("radius", [1, 2])
+def test_zero_copy_batch_server(pkg, L, O, torch_cuda, radius):
+    """The default path of pinned host-to-host submits: ONE long-lived dispatch (blur_server_kernel) takes batch after batch
+    from a descriptor ring, tiles handed out by a ticket counter that runs through the batches, completion per batch
+    signalled into host memory.  Bit-exact vs the oracle for: a back-to-back stream on rotating buffers; a producer slower
+    than the server's idle time-out (every batch finds the server gone and the queued one picks it up); a budget of 3
+    batches per server (roll-over to the next queued server in mid-stream); 1, 5 and 300 workers (fewer / more workers than
+    tiles); several contexts at once; batches of different sizes and a band submit of another geometry in between (that
+    one takes the per-batch launch); destroy right after the last submit."""
+    h, w, c, n = 96, 320, 3, 9
+    rounds, nbuf = 5, 4
+    host = O.lcg_stream(nbuf * n, h, w, c, first_index=300)
+    want = O.blur_batch(host, radius)
+    nbytes = n * h * w * c
+    bufs = [(L.mi_blur_host_alloc(nbytes), L.mi_blur_host_alloc(nbytes)) for _ in range(nbuf)]
+    as_np = lambda ptr, m=n: np.ctypeslib.as_array((C.c_uint8 * (m * h * w * c)).from_address(ptr)).reshape(m, h, w, c)
+    try:
+        for k, (pi, _po) in enumerate(bufs):
+            C.memmove(pi, host[k * n:(k + 1) * n].ctypes.data, nbytes)
+
+        def run(ctx, delay=0.0, sizes=None):
+            for (_pi, po) in bufs:
+                C.memset(po, 0xEE, nbytes)
+            for rnd in range(rounds):
+                for k, (pi, po) in enumerate(bufs):
+                    if delay:
+                        time.sleep(delay)
+                    ctx.submit(pi, po, sizes[k] if sizes else n)
+            tm = ctx.sync()
+            for k, (_pi, po) in enumerate(bufs):
+                m = sizes[k] if sizes else n
+                assert np.array_equal(as_np(po)[:m], want[k * n:k * n + m]), k
+                assert bool((as_np(po)[m:] == 0xEE).all())
+            return tm
+
+        for opts, delay in (({}, 0.0), ({"zero_copy_idle_us": 50}, 0.002), ({"zero_copy_budget": 3}, 0.0), ({"zero_copy_workers": 1}, 0.0),
+                            ({"zero_copy_workers": 5}, 0.0), ({"zero_copy_workers": 300}, 0.0)):
+            for key, v in opts.items():
+                pkg.check(L.mi_blur_set_option(key.encode(), v))
+            try:
+                with pkg.Context(0, w, h, c, radius, max_batch=n, n_slots=nbuf) as ctx:
+                    t0 = time.perf_counter()
+                    tm = run(ctx, delay)
+                    wall_ms = (time.perf_counter() - t0) * 1e3
+                    assert L.mi_blur_zero_copy_launches(ctx.h) == rounds * nbuf and L.mi_blur_last_kernel() == b"blur_server_kernel"
+                    assert tm["images"] == rounds * nbuf * n and 0 < tm["kernel_ms"] <= wall_ms * 1.02 + 0.05, (opts, tm, wall_ms)
+                    assert tm["h2d_ms"] == 0 and tm["d2h_ms"] == 0               # the transfer time IS the kernel bucket
+                    run(ctx, sizes=[n, 1, 4, n - 1])                             # batches of different sizes through the same server
+            finally:
+                for key, v in (("zero_copy_idle_us", 300), ("zero_copy_budget", 256), ("zero_copy_workers", 48)):
+                    pkg.check(L.mi_blur_set_option(key.encode(), v))
+
+        # three contexts side by side (each has its own server), fed in turn
+        ctxs = [pkg.Context(0, w, h, c, radius, max_batch=n, n_slots=2) for _ in range(3)]
+        outs = [[L.mi_blur_host_alloc(nbytes) for _ in range(nbuf)] for _ in ctxs]
+        for rnd in range(3):
+            for k in range(nbuf):
+                for ci, ctx in enumerate(ctxs):
+                    ctx.submit(bufs[k][0], outs[ci][k], n)
+        for ci, ctx in enumerate(ctxs):
+            ctx.sync()
+            for k in range(nbuf):
+                assert np.array_equal(as_np(outs[ci][k]), want[k * n:(k + 1) * n]), (ci, k)
+        # a band submit of another geometry in between takes the per-batch launch; the server carries on afterwards
+        ctx = ctxs[0]
+        one = np.ascontiguousarray(host[0])
+        p_one, p_top = L.mi_blur_host_alloc(one.nbytes), L.mi_blur_host_alloc(one.nbytes)
+        C.memmove(p_one, one.ctypes.data, one.nbytes)
+        ctx.submit(bufs[1][0], outs[0][1], n)
+        ctx.submit_band(p_one, p_top, 39 + radius, 0, radius)
+        ctx.submit(bufs[2][0], outs[0][2], n)
+        ctx.sync()
+        assert np.array_equal(np.ctypeslib.as_array((C.c_uint8 * (39 * w * c)).from_address(p_top)).reshape(39, w, c), want[0][:39])
+        assert np.array_equal(as_np(outs[0][1]), want[n:2 * n]) and np.array_equal(as_np(outs[0][2]), want[2 * n:3 * n])
+        # destroy with work just submitted: the context drains it, tells its servers to leave and waits for them
+        ctxs[1].submit(bufs[3][0], outs[1][3], n)
+        for ctx in ctxs:
+            ctx.close()
+        assert np.array_equal(as_np(outs[1][3]), want[3 * n:4 * n])
+        for o in outs:
+            for ptr in o:
+                L.mi_blur_host_free(ptr)
+        L.mi_blur_host_free(p_one); L.mi_blur_host_free(p_top)
+    finally:
         for (pi, po) in bufs:
             L.mi_blur_host_free(pi); L.mi_blur_host_free(po)
 
