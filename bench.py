@@ -61,6 +61,7 @@ os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "0")   # before any HIP initialis
 import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+LINK_ONE_WAY_GBS = 56.4          # profiles/r01_pcie_probe.txt: measured one-way DMA rate of this host link (256 MiB copies; 52.6 at 7 MiB)
 REFERENCE_IMG_S = 8568.10        # data/approach1/35_run_1.txt:79 — 320x240, i7-12700 + UHD 770 together
 CONFIG3_IMAGES = 50000           # BASELINE configs[3]: 50 000 images over the node
 SECONDARY_WARM_S = 0.25          # untimed launches before each secondary point: after ANY idle gap the first ~40 ms of
@@ -495,8 +496,9 @@ def main() -> None:
         te = e2e.sync()
         dte = time.perf_counter() - t0e
         res = {"img_s": round(nbatches * nb / dte, 0), "batch": nb, "batches": nbatches, "slots": NS,
-               "zero_copy_submits": int(L.mi_blur_zero_copy_launches(e2e.h)),
+               "zero_copy_submits": int(L.mi_blur_zero_copy_launches(e2e.h)), "kernel": L.mi_blur_last_kernel().decode(),
                "pcie_gbs_each_way": round(nbatches * nbytes / dte / 1e9, 1),
+               "frac_of_link": round(nbatches * nbytes / dte / 1e9 / LINK_ONE_WAY_GBS, 3),
                "h2d_ms": round(te["h2d_ms"], 2), "kernel_ms": round(te["kernel_ms"], 2), "d2h_ms": round(te["d2h_ms"], 2)}
         for (pi, po) in bufs:
             L.mi_blur_host_free(pi); L.mi_blur_host_free(po)
@@ -956,9 +958,11 @@ def main() -> None:
             extra["hd1080_5x5"] = point_resident(1920, 1080, 3, 2, 64, 64, 64, 300,
                                                  "64 x 1920x1080x3 per launch, 5x5, resident pool of 64 (configs[2])")
             extra["a2_8192_1gpu"] = point_a2_1gpu(300)
-            extra["e2e_pcie_inclusive"] = {"batch_35": point_e2e(256, 256, 3, 1, 35, 143 * 2),
+            extra["e2e_pcie_inclusive"] = {"batch_35": point_e2e(256, 256, 3, 1, 35, 143 * 4),
                                            "batch_500": point_e2e(256, 256, 3, 1, 500, 40),
-                                           "note": "pinned host buffers in and out, kernel works on them in place over PCIe; "
+                                           "link_one_way_gbs": LINK_ONE_WAY_GBS,
+                                           "note": "pinned host buffers in and out, the batch server's workgroups work on them in place over PCIe "
+                                                   "(both directions at once; frac_of_link = each-way rate / the measured ONE-way DMA rate); "
                                                    "comparable to the reference's wall clock (heterogeneous_blur.c:415,603)"}
         base_shape = (h, w, c, radius)
     else:   # a2: one 8192x8192x3 image, row-split, RCCL halo exchange

@@ -557,7 +557,7 @@ static_assert(sizeof(ZcBatch) / 4 <= 64, "the poller copies a descriptor with on
 
 template <int C, int R, int RPG>
 __global__ __launch_bounds__(256) void blur_server_kernel(ZcHostCtl *ctl, ZcDevCtl *dev, unsigned seq, unsigned budget, unsigned idle_ticks,
-                                                          unsigned long long *trace)
+                                                          unsigned long long *trace, int fixed_share)
 {
     const unsigned NW = gridDim.x - 1;
     // where the previous server stopped (its dispatch is complete: same stream).  This server's poller writes the OTHER words.
@@ -686,7 +686,10 @@ __global__ __launch_bounds__(256) void blur_server_kernel(ZcHostCtl *ctl, ZcDevC
             count_pending();
         }
     };
-    if (threadIdx.x == 0) s_ctl[1] = __hip_atomic_fetch_add(&dev->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // fixed_share (A/B only, "zero_copy_tickets" 0): worker w takes global tiles w, w + NW, ... — the share a per-batch launch
+    // gives a workgroup — instead of drawing tickets
+    if (threadIdx.x == 0)
+        s_ctl[1] = fixed_share ? dev->gnext[seq & 1u] + w : __hip_atomic_fetch_add(&dev->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     unsigned t = s_ctl[1];
     unsigned long long *tr = nullptr;
@@ -749,7 +752,8 @@ __global__ __launch_bounds__(256) void blur_server_kernel(ZcHostCtl *ctl, ZcDevC
         // ---- draw the next ticket now (its round trip hides behind the tile), then the tile
         // (two LDS words, taken in turn: a wave that is already drawing for the next tile must not overwrite the word a slower
         // wave of the block has not read yet — the barriers of one whole tile lie between two writes of the same word)
-        if (threadIdx.x == 0) s_ctl[2u + (it & 1u)] = __hip_atomic_fetch_add(&dev->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0)
+            s_ctl[2u + (it & 1u)] = fixed_share ? t + NW : __hip_atomic_fetch_add(&dev->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long t_a = trace ? wall_clock64() : 0ull;
         tiled_tile<C, R, RPG, true, false, false, false, rowpass_default<R>>(u.p, t - tile_first, count_pending);
         pending = k % ZC_RING;
@@ -1050,7 +1054,11 @@ static std::mutex &tunables_mutex() { static std::mutex m; return m; }
 static Tunables &tunables_storage()
 {
     static Tunables t = [] {
-        Tunables v{1, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0, 4, 24, 1, 1, 8, 0, 8, 1, 48, 300, 256, 0, 1};  // rpg 0 / stream_bh 0 = choose per launch
+        Tunables v{};                                    // everything 0 / off unless named here (rpg 0 / stream_bh 0 = choose per launch)
+        v.stage_dma = 1; v.xcd_remap = 1; v.zero_copy = 1; v.ragged = 1;
+        v.zero_copy_streams = 4; v.zero_copy_blocks = 24; v.stream_updown = 1; v.prefer_direct = 1; v.direct_bh = 8; v.fused_window = 8;
+        v.zero_copy_server = 1; v.zero_copy_workers = 48; v.zero_copy_idle_us = 300; v.zero_copy_budget = 256; v.zero_copy_tickets = 1;
+        v.zero_copy_events = 1;
         if (const char *e = getenv("MI_BLUR_STAGE")) v.stage_dma = strcmp(e, "reg") != 0;
         if (const char *e = getenv("MI_BLUR_RPG")) { const int r = atoi(e); v.rpg = (r == 4 || r == 8 || r == 16) ? r : 0; }
         if (const char *e = getenv("MI_BLUR_XCD")) v.xcd_remap = atoi(e) != 0;
@@ -1300,13 +1308,13 @@ int zc_fill_batch(const LaunchDesc &d, ZcGeometry *geo, ZcBatch *b, unsigned *n_
 }
 
 int zc_launch_server(const ZcGeometry &geo, ZcHostCtl *ctl, ZcDevCtl *dev, unsigned seq, unsigned n_workers, unsigned budget,
-                     unsigned idle_ticks, hipStream_t stream, unsigned long long *trace)
+                     unsigned idle_ticks, hipStream_t stream, unsigned long long *trace, int fixed_share)
 {
     if (!ctl || !dev || n_workers == 0 || geo.threads == 0 || geo.rpg != 4) return MI_BLUR_ERR_INVALID;
     g_last_kernel = "blur_server_kernel";
     const dim3 grid(n_workers + 1), block(geo.threads);
     auto go = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, grid, block, geo.lds, stream, ctl, dev, seq, budget, idle_ticks, trace);
+        hipLaunchKernelGGL(kernel, grid, block, geo.lds, stream, ctl, dev, seq, budget, idle_ticks, trace, fixed_share);
         return hip_status(hipGetLastError());
     };
     switch (geo.channels * 10 + geo.radius) {

@@ -91,7 +91,7 @@ struct ZcGeometry { unsigned threads; size_t lds; int rpg; int channels, radius;
 // filled on the first call (geo->threads == 0) and must match on later ones (MI_BLUR_ERR_UNSUPPORTED otherwise).
 int zc_fill_batch(const LaunchDesc &d, ZcGeometry *geo, ZcBatch *b, unsigned *n_tiles);
 int zc_launch_server(const ZcGeometry &geo, ZcHostCtl *ctl, ZcDevCtl *dev, unsigned seq, unsigned n_workers, unsigned budget,
-                     unsigned idle_ticks, hipStream_t stream, unsigned long long *trace = nullptr);
+                     unsigned idle_ticks, hipStream_t stream, unsigned long long *trace = nullptr, int fixed_share = 0);
 
 // Name of the kernel the calling thread's most recent launch() / launch_fused() chose ("" before the first).
 const char *last_kernel();
@@ -122,6 +122,7 @@ struct Tunables {
     int zero_copy_workers; // batch server: worker workgroups (default 48: 40-64 measured best, profiles/r03_e2e_timeline.md)
     int zero_copy_idle_us; // batch server: leaves after this long without a new batch (default 300)
     int zero_copy_budget;  // batch server: leaves after this many batches, the queued next one carries on (default 256)
+    int zero_copy_tickets; // batch server: 1 (default) = tiles by ticket counter, 0 = fixed share per worker (tile g to worker g mod n; A/B only)
     int zero_copy_trace;   // diagnostics: the batch server's workers stamp their phases per batch (mi_blur_debug_zc_trace)
     int zero_copy_events; // zero-copy submits: 1 = the dispatch carries start/stop timestamp events (kernel bucket + completion),
                          // 0 = plain launch, completion by stream synchronise (timing experiment: no kernel bucket)

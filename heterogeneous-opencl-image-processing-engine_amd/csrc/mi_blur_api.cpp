@@ -102,6 +102,7 @@ extern "C" int mi_blur_set_option(const char *key, int value)
     else if (!strcmp(key, "zero_copy_events")) t.zero_copy_events = value != 0;
     else if (!strcmp(key, "zero_copy_server")) t.zero_copy_server = value != 0;
     else if (!strcmp(key, "zero_copy_trace")) t.zero_copy_trace = value != 0;
+    else if (!strcmp(key, "zero_copy_tickets")) t.zero_copy_tickets = value != 0;
     else if (!strcmp(key, "zero_copy_workers")) { if (value < 1 || value > 2048) return MI_BLUR_ERR_INVALID; t.zero_copy_workers = value; }
     else if (!strcmp(key, "zero_copy_idle_us")) { if (value < 10 || value > 100000) return MI_BLUR_ERR_INVALID; t.zero_copy_idle_us = value; }
     else if (!strcmp(key, "zero_copy_budget")) { if (value < 1 || value > (1 << 20)) return MI_BLUR_ERR_INVALID; t.zero_copy_budget = value; }
@@ -193,6 +194,7 @@ struct ZcServer {
     unsigned n_workers = 96, budget = 256, idle_ticks = 30000;
     unsigned long long covered = 0;                      // kernel bucket: the union of [t_begin, t_end] so far reaches this tick
     unsigned long long *trace = nullptr;                 // diagnostics ("zero_copy_trace"): device buffer of per-worker phase stamps
+    int fixed_share = 0;                                 // A/B: "zero_copy_tickets" 0
 };
 
 struct CpuJob {
@@ -605,6 +607,7 @@ static int zc_server_submit(mi_blur_ctx *c, Slot &s, const LaunchDesc &d, const 
             delete z;
             return MI_BLUR_ERR_HIP_BASE - (int)e;
         }
+        z->fixed_share = tun.zero_copy_tickets ? 0 : 1;
         z->n_workers = (unsigned)tun.zero_copy_workers;
         z->budget = (unsigned)tun.zero_copy_budget;
         z->idle_ticks = (unsigned)tun.zero_copy_idle_us * 100u;      // 100 MHz device clock
@@ -630,7 +633,7 @@ static int zc_server_submit(mi_blur_ctx *c, Slot &s, const LaunchDesc &d, const 
     // this batch is published; the one queued behind it on the same stream then takes it.
     const unsigned stopped = __atomic_load_n(&z.ctl->servers_done, __ATOMIC_ACQUIRE);
     while (z.launched - stopped < 2u) {
-        rc = zc_launch_server(z.geo, z.ctl_dev, z.dev, z.launched, z.n_workers, z.budget, z.idle_ticks, z.stream, z.trace);
+        rc = zc_launch_server(z.geo, z.ctl_dev, z.dev, z.launched, z.n_workers, z.budget, z.idle_ticks, z.stream, z.trace, z.fixed_share);
         if (rc) return rc;
         z.launched++;
     }
