@@ -487,8 +487,11 @@ def main() -> None:
         bufs = [(L.mi_blur_host_alloc(nbytes), L.mi_blur_host_alloc(nbytes)) for _ in range(NS)]
         for (pi, _po) in bufs:
             L.mi_blur_fill_synthetic(pi, w, h, c, 0, nb, 4)
-        for i in range(2 * NS):
+        warm_until = time.perf_counter() + SECONDARY_WARM_S       # filling the buffers left GPU and link idle: ramp both again
+        i = 0
+        while time.perf_counter() < warm_until or i < 2 * NS:
             e2e.submit(bufs[i % NS][0], bufs[i % NS][1], nb)
+            i += 1
         e2e.sync(); e2e.reset_timing()
         t0e = time.perf_counter()
         for i in range(nbatches):

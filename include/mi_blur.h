@@ -88,6 +88,17 @@ const char *mi_blur_last_kernel(void);
  *                      tiled kernel; 0 = they take the generic one-byte-per-thread kernel
  *   "zero_copy"        1 (default) = submits whose input AND output are pinned host memory run the kernel on the
  *                      caller's buffers in place (no staging copies); 0 = always H2D -> kernel -> D2H
+ *   "zero_copy_server"  1 (default) = zero-copy submits of aligned shapes go through the context's BATCH SERVER: one long-lived
+ *                      dispatch (blur_server_kernel) takes batch after batch from a descriptor ring in pinned memory, hands the
+ *                      tiles out through one ticket counter that runs through the batches and signals each complete batch
+ *                      into host memory — no launch per batch, and no batch waiting for its unluckiest workgroup (+27 % images/s
+ *                      end to end at batch 35, profiles/r03_e2e_timeline.md); 0 = one capped launch per batch (the two knobs below)
+ *   "zero_copy_workers" 48 (default): the server's worker workgroups (read when a context's server is made)
+ *   "zero_copy_idle_us" 300 (default): a server leaves after this long without a new batch (the next submit starts one)
+ *   "zero_copy_budget"  256 (default): ... and after this many batches; the next one, already queued behind it, carries on
+ *   "zero_copy_tickets" 1 (default) | 0 = a fixed share of tiles per worker (A/B runs: what a per-batch launch does)
+ *   "zero_copy_trace"   0 (default) | 1 = the server's workers stamp their phases (mi_blur_debug_zc_trace)
+ *   "zero_copy_events"  1 (default) | 0 = per-batch launches carry no timestamp events (timing experiment; no kernel bucket)
  *   "zero_copy_streams" 4 (default): zero-copy submits of a context alternate over this many of its streams (at most n_slots)
  *   "zero_copy_blocks"  24 (default): zero-copy launches of the aligned tiled kernel keep at most this many workgroups
  *                      resident, each looping over tiles (0 = one workgroup per tile).  The host link needs ~100 KB in
@@ -162,6 +173,8 @@ void mi_blur_destroy(mi_blur_ctx *ctx);
  * from here (or are otherwise pinned) the kernel works on them in place over PCIe — the counterpart of
  * CL_MEM_USE_HOST_PTR on the reference's shared-memory iGPU, and the fastest end-to-end form on this
  * platform; the h2d/d2h buckets of such a submit are ~0 and the transfer time is inside kernel_ms.
+ * Such submits are batches of the context's batch server (see "zero_copy_server"): the submit publishes a descriptor,
+ * mi_blur_wait_oldest / mi_blur_sync spin on the batch's completion word in host memory.
  * With only one side pinned, or "zero_copy" off, submit() DMA-copies straight from/to pinned memory;
  * ordinary (pageable) caller memory is accepted too and goes through the slot's own pinned staging
  * buffers (one extra host memcpy each way). */

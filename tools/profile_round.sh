@@ -6,7 +6,8 @@
 # For each bench configuration: (0) the plain bench line, (1) kernel trace + stats of the same command,
 # (2)+(3) separate PMC passes (FETCH_SIZE, WRITE_SIZE) with kernel-trace only, as MI355X_MICROARCH.md prescribes.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
+PART=${2:-all}          # all | a (the a1 forms) | b (hd5, a2_1gpu, counter passes): two gpurun calls when one would be too long
 OUT=/root/repo/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /root/repo
@@ -24,10 +25,13 @@ run_cfg() {   # name, bench args...
     echo "$name write rc=$?"
 }
 
+if [ $PART != b ]; then
 run_cfg a1                                                                  # the judged command: python bench.py (fused stream + every secondary point)
 run_cfg a1_batched --dispatch batched --no-cpu-baseline --no-extra           # one launch per batch, 4 streams
 run_cfg a1_serial --dispatch batched --streams 1 --time-every 4 --no-cpu-baseline --no-extra   # same launches, one stream: dispatches do not overlap
 run_cfg a1_one_launch --batch 5000 --streams 1 --time-every 1 --no-cpu-baseline --no-extra   # whole stream in one launch (HBM-bound point)
+fi
+if [ $PART != a ]; then
 run_cfg hd5 --workload hd5 --streams 1 --no-cpu-baseline                    # BASELINE configs[2]: 1920x1080 5x5
 run_cfg a2_1gpu --workload a2 --no-cpu-baseline                             # BASELINE configs[4] at N=1: 8192x8192 3x3
 
@@ -47,4 +51,5 @@ for w in a1 hd5; do
     pmc ${w}_lds SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS -- $extra
     pmc ${w}_tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum -- $extra
 done
+fi
 echo "done"; du -sh $OUT
