@@ -3,7 +3,7 @@
 //   heterogeneous_blur {cpu|gpu|both} [gpu_ratio] [batch]  [--image F | --synthetic | --size WxH] [--channels C]
 //                      [--ksize 3|5] [--images N] [--gpus G] [--slots S] [--threads T] [--resident [--fused]]
 //                      [--verbose] [--csv FILE] [--save FILE]
-//                      [--frames DIR|PATTERN|FILE [--save-dir DIR] [--planar-out]]   (cpu | gpu)
+//                      [--frames DIR|PATTERN|FILE [--save-dir DIR] [--planar-out | --native-layout]]   (cpu | gpu)
 //
 // Same positional command line, banner and report sections as the reference host
 // (heterogeneous_blur.c:41-100 CLI, :406-601 batch loop, :609-724 report).  What changed:
@@ -489,13 +489,31 @@ static int run_frames(const Options &opt, int mode, int BATCH_SIZE, const std::v
     if (mode == 2 && !gpus_available(G)) { printf("Error: Could not find %d GPU device(s) (%d visible)\n", G < 1 ? 1 : G, mi_blur_device_count()); return -1; }
     const int per_dev_slots = opt.slots_given ? opt.slots : 3;
     const int S = per_dev_slots * G;
+    // Three ways through the device, by what goes in and what is wanted out:
+    //   planar in -> interleaved out   mi_blur_submit_planar: GPU repack-in (reads the frames over the host link), blur in HBM, copy out
+    //   planar in -> planar out        no repack at all: a planar batch IS a batch of n*C one-channel images (mi_blur_submit on a C = 1
+    //                                  context; pinned buffers, so the batch server blurs them in place over PCIe)
+    //   --native-layout                the file format is interleaved on disk (PPM/PGM): read straight into the pinned interleaved batch
+    //                                  buffer and mi_blur_submit (batch server) — no host de-interleave, no GPU repack
+#ifdef MI_BLUR_WITH_CIMG
+    const bool native = false;                     // CImg hands every format over planar
+    if (opt.native_layout) printf("Note: --native-layout ignored in a CImg build (CImg storage is planar)\n");
+#else
+    const bool native = opt.native_layout;
+#endif
+    if (native && opt.planar_out) { printf("Error: --native-layout and --planar-out exclude each other\n"); return -1; }
+    const bool planes_as_images = !native && opt.planar_out;
+    const int ctx_channels = planes_as_images ? 1 : channels, per_frame = planes_as_images ? channels : 1;
     std::vector<mi_blur_ctx *> ctx(G, nullptr);
     for (int g = 0; g < G; g++) {
-        mi_check(mi_blur_create(&ctx[g], mode == 1 ? MI_BLUR_DEVICE_CPU : hip_ordinal(g), width, height, channels, radius, BATCH_SIZE, per_dev_slots,
-                                opt.threads), "Failed to create context");
+        mi_check(mi_blur_create(&ctx[g], mode == 1 ? MI_BLUR_DEVICE_CPU : hip_ordinal(g), width, height, ctx_channels, radius, BATCH_SIZE * per_frame,
+                                per_dev_slots, opt.threads), "Failed to create context");
         if (mode == 2) { printf("GPU device: HIP device %d\n", hip_ordinal(g)); report_placement(g, hip_ordinal(g), g == 0); }
         else printf("CPU device: host threads\n");
     }
+    printf("Frame path: %s\n", native ? "interleaved on disk -> pinned interleaved batch -> blur in place (no repack anywhere)"
+                               : planes_as_images ? "planar frames blurred as one-channel images, in place (no repack anywhere)"
+                                                  : "planar frames -> GPU repack-in -> blur -> interleaved out");
     std::vector<uint8_t *> in(S, nullptr), out(S, nullptr);
     for (int s = 0; s < S; s++) {
         const int g = s % G;
@@ -520,10 +538,19 @@ static int run_frames(const Options &opt, int mode, int BATCH_SIZE, const std::v
     };
     auto batch_range = [&](int k, int &first, int &n) { first = k * BATCH_SIZE; n = std::min(BATCH_SIZE, N - first); };
 
+    // Warm-up outside the clock, as in the other modes: first-use costs (code-object load, the batch server's control
+    // blocks and first launch: ~15 ms) would otherwise sit in the first batch of a stream that takes a few tens of ms.
+    for (int g = 0; g < G; g++) {
+        memset(in[g], 0, image_size);
+        if (native || planes_as_images) mi_check(mi_blur_submit(ctx[g], in[g], out[g], per_frame), "warm-up failed");
+        else mi_check(mi_blur_submit_planar(ctx[g], in[g], out[g], 1, 0), "warm-up failed");
+        mi_check(mi_blur_sync(ctx[g], nullptr), "warm-up failed");
+        mi_blur_reset_timing(ctx[g]);
+    }
     printf("\nStarting frame stream: %d frames in %d batches of up to %d, %d helper thread(s), %d buffer set(s) per device%s%s\n\n", N, NB, BATCH_SIZE,
            pool.threads(), per_dev_slots, opt.planar_out ? ", planar output" : "", opt.save_dir.empty() ? "" : ", saving every frame");
     const double t0 = get_time_ms();
-    double wait_ms = 0;
+    double wait_ms = 0, phase_ms = 0, submit_ms = 0;
     for (int k = 0; k < NB + S; k++) {
         const int s = k % S;
         int old_first = 0, old_n = 0, first = 0, n = 0;
@@ -536,6 +563,7 @@ static int run_frames(const Options &opt, int mode, int BATCH_SIZE, const std::v
         }
         if (have_new) batch_range(k, first, n);
         const int n_save = (have_old && !opt.save_dir.empty()) ? old_n : 0;
+        const double p0 = get_time_ms();
         pool.run(n_save + (have_new ? n : 0), [&](int item, int t) {
             const double a = get_time_ms();
             if (item < n_save) {
@@ -543,10 +571,12 @@ static int run_frames(const Options &opt, int mode, int BATCH_SIZE, const std::v
                 save_ms[t] += get_time_ms() - a;
             } else {
                 const int j = item - n_save;
-                if (!decode_frame_planar(files[first + j], in[s] + (size_t)j * image_size, width, height, channels, scratch[t])) failed++;
+                if (!(native ? read_pnm_interleaved(files[first + j], in[s] + (size_t)j * image_size, width, height, channels)
+                             : decode_frame_planar(files[first + j], in[s] + (size_t)j * image_size, width, height, channels, scratch[t]))) failed++;
                 decode_ms[t] += get_time_ms() - a;
             }
         });
+        phase_ms += get_time_ms() - p0;
         if (failed.load()) {
             printf("Error: a frame could not be read (or differs from %dx%dx%d) or written\n", width, height, channels);
             for (auto c : ctx) { (void)mi_blur_sync(c, nullptr); mi_blur_destroy(c); }        // work already submitted drains first
@@ -555,7 +585,11 @@ static int run_frames(const Options &opt, int mode, int BATCH_SIZE, const std::v
         }
         if (have_new) {
             if (opt.verbose) printf("  Batch %d/%d: frames %d-%d -> device %d\n", k + 1, NB, first, first + n - 1, k % G);
-            mi_check(mi_blur_submit_planar(ctx[k % G], in[s], out[s], n, opt.planar_out ? 1 : 0), "submit failed");
+            const double s0 = get_time_ms();
+            if (native || planes_as_images) mi_check(mi_blur_submit(ctx[k % G], in[s], out[s], n * per_frame), "submit failed");
+            else mi_check(mi_blur_submit_planar(ctx[k % G], in[s], out[s], n, 0), "submit failed");
+            submit_ms += get_time_ms() - s0;
+            if (opt.verbose) printf("    submit %d took %.3f ms\n", k, get_time_ms() - s0);
         }
     }
     DeviceTimes td;
@@ -571,17 +605,20 @@ static int run_frames(const Options &opt, int mode, int BATCH_SIZE, const std::v
     printf("\n====================\n\n");
     const Throughput thr = report_throughput(N, width, height, wall);
     printf("10. FRAME INGEST (distinct frames; ingest-inclusive figures)\n");
-    printf("   Frames: %d files, decoded into pinned PLANAR batch buffers by %d helper thread(s)\n", N, pool.threads());
+    printf("   Frames: %d files, %s by %d helper thread(s)\n", N, native ? "read into pinned INTERLEAVED batch buffers" : "decoded into pinned PLANAR batch buffers", pool.threads());
     printf("   Decode:            %.2f ms of helper-thread time (%.4f ms per frame)\n", dsum, dsum / N);
-    if (mode == 2) {
+    if (mode == 2 && (native || planes_as_images)) {
+        printf("   GPU blur in place: %.2f ms (the batch server reads and writes the pinned frames over the host link)\n", td.kernel_ms);
+    } else if (mode == 2) {
         printf("   GPU repack-in:     %.2f ms (planar frames read over the host link, interleaved batch written to HBM)\n", td.in_ms);
         printf("   GPU blur:          %.2f ms\n", td.kernel_ms);
-        printf("   GPU %s %.2f ms\n", opt.planar_out ? "repack-out:   " : "copy-out:     ", td.out_ms);
+        printf("   GPU copy-out:      %.2f ms\n", td.out_ms);
     } else {
         printf("   CPU repack + blur: %.2f ms\n", td.kernel_ms);
     }
     if (!opt.save_dir.empty()) printf("   Save:              %.2f ms of helper-thread time (%.4f ms per frame) -> %s\n", ssum, ssum / N, opt.save_dir.c_str());
     printf("   Host blocked waiting for a device: %.2f ms of %.2f ms wall\n", wait_ms, wall);
+    printf("   Feeder thread: %.2f ms in decode/save phases (with the helpers), %.2f ms in submits\n", phase_ms, submit_ms);
     printf("   Ingest-inclusive throughput: %.2f images/sec (%.2f Megapixels/sec)\n\n", thr.img_s, thr.mpix);
     Roofline rf;
     if (mode == 2) { rf = report_roofline(9, G, bytes_alg, launches, td.kernel_ms, N); printf("\n"); }

@@ -181,7 +181,10 @@ struct Options {
     std::string frames;                  // --frames DIR|PATTERN|FILE  (heterogeneous_blur cpu|gpu): a stream of DISTINCT frames, decoded
                                          //              by the helper threads into pinned PLANAR batch buffers, repacked on the GPU
     std::string save_dir;                // --save-dir DIR   (with --frames) write every blurred frame as DIR/<name>.ppm|.pgm
-    bool planar_out = false;             // --planar-out     (with --frames) outputs come back planar (GPU repack-out kernel)
+    bool planar_out = false;             // --planar-out     (with --frames) outputs come back planar; the planar frames are then blurred as
+                                         //              C one-channel images each — no repack at all (batch server, in place over PCIe)
+    bool native_layout = false;          // --native-layout  (with --frames) a file format that is interleaved on disk (PPM/PGM) is read straight
+                                         //              into the pinned INTERLEAVED batch buffer: no host de-interleave, no GPU repack
 };
 
 // Returns the number of leading positional arguments (those before the first "--flag").
@@ -217,6 +220,7 @@ inline int parse_flags(int argc, char **argv, Options &o)
         else if (a == "--frames") o.frames = next("--frames");
         else if (a == "--save-dir") o.save_dir = next("--save-dir");
         else if (a == "--planar-out") o.planar_out = true;
+        else if (a == "--native-layout") o.native_layout = true;
         else if (a == "--transport") { o.transport = next("--transport"); if (o.transport != "rccl" && o.transport != "p2p") { printf("Error: --transport rccl|p2p\n"); exit(-1); } }
         else { printf("Error: unknown option %s\n", a.c_str()); exit(-1); }
     }
@@ -393,6 +397,21 @@ inline bool decode_frame_planar(const std::string &path, uint8_t *planar, int w,
                 }
         }
     }
+    fclose(f);
+    return ok;
+}
+
+// A PPM/PGM frame as it lies on disk — interleaved — straight into `dst` (w*h*c bytes of the pinned batch buffer).
+inline bool read_pnm_interleaved(const std::string &path, uint8_t *dst, int w, int h, int c)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char magic[3] = {0, 0, 0};
+    int fw = 0, fh = 0, maxv = 0;
+    bool ok = fread(magic, 1, 2, f) == 2 && magic[0] == 'P' && (magic[1] == '6' || magic[1] == '5') && skip_ws_comments(f) &&
+              fscanf(f, "%d", &fw) == 1 && skip_ws_comments(f) && fscanf(f, "%d", &fh) == 1 && skip_ws_comments(f) &&
+              fscanf(f, "%d", &maxv) == 1 && maxv == 255 && fw == w && fh == h && (magic[1] == '6' ? 3 : 1) == c;
+    if (ok) { fgetc(f); const size_t n = (size_t)w * h * c; ok = fread(dst, 1, n, f) == n; }
     fclose(f);
     return ok;
 }

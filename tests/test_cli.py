@@ -118,6 +118,11 @@ def test_frames_stream_on_the_cpu_device(apps, O, tmp_path):
     r = run([het, "cpu", "0.5", "4", "--frames", "in", "--save-dir", "out3", "--planar-out"], tmp_path)
     assert r.returncode == 0
     _check_saved_frames(O, tmp_path / "out3", frames, 1)
+    r = run([het, "cpu", "0.5", "4", "--frames", "in", "--save-dir", "out4", "--native-layout", "--ksize", "5"], tmp_path)
+    assert r.returncode == 0 and "interleaved on disk -> pinned interleaved batch" in r.stdout
+    _check_saved_frames(O, tmp_path / "out4", frames, 2)
+    r = run([het, "cpu", "0.5", "4", "--frames", "in", "--native-layout", "--planar-out"], tmp_path)
+    assert r.returncode != 0 and "exclude each other" in r.stdout
     # errors: nothing found; both devices at once; a frame of another size in the stream
     r = run([het, "cpu", "0.5", "4", "--frames", "nowhere"], tmp_path)
     assert r.returncode != 0 and "Error: no frame files found" in r.stdout
@@ -143,9 +148,14 @@ def test_frames_stream_on_the_gpu(apps, O, tmp_path):
     _check_saved_frames(O, tmp_path / "out", frames, 1)
     row, = read_csv(tmp_path / "f.csv")
     assert row["mode"] == "gpu-frames" and row["images"] == "96" and float(row["gpu_in_ms"]) > 0 and float(row["gpu_kernel_ms"]) > 0
+    # planar out: the planar frames are blurred as one-channel images, in place over PCIe (batch server) — no repack at all
     r = run([het, "gpu", "1.0", "20", "--frames", "in", "--save-dir", "out5", "--ksize", "5", "--planar-out", "--slots", "2"], tmp_path)
-    assert r.returncode == 0 and "GPU repack-out:" in r.stdout, r.stdout + r.stderr
+    assert r.returncode == 0 and "planar frames blurred as one-channel images" in r.stdout and "GPU blur in place:" in r.stdout, r.stdout + r.stderr
     _check_saved_frames(O, tmp_path / "out5", frames, 2)
+    # native layout: PPM is interleaved on disk, so it is read straight into the pinned interleaved batch buffer
+    r = run([het, "gpu", "1.0", "35", "--frames", "in", "--save-dir", "out6", "--native-layout"], tmp_path)
+    assert r.returncode == 0 and "interleaved on disk -> pinned interleaved batch" in r.stdout and "GPU blur in place:" in r.stdout, r.stdout + r.stderr
+    _check_saved_frames(O, tmp_path / "out6", frames, 1)
     # two logical GPUs (batch k -> GPU k % 2), grey frames whose plane is not a multiple of 16 pixels (byte repack kernel, ragged blur)
     grey = _write_frames(O, tmp_path / "g", 40, 167, 250, 1, pattern="g%02d")
     r = subprocess.run([het, "gpu", "1.0", "7", "--frames", "g", "--save-dir", "gout", "--gpus", "2"], cwd=tmp_path, capture_output=True, text=True,
