@@ -374,6 +374,13 @@ def test_bench_spawns_its_own_ranks(pkg):
     assert a2["rccl_ranks"] == 0 and "rehearsal" in a2                    # exchange leg left out on a one-GPU box, and the line says so
     pa = d["parity"]["a2_8192_rowsplit"]
     assert pa["ok"] and set(pa["band_fnv"]) == {"plain", "overlapped"} and pa["band_fnv"]["plain"] == pa["band_fnv"]["overlapped"] == "0d04249de0140100"
+    # the configs[3] line survives a configs[4] leg that never completes (a stuck exchange on the first real multi-GPU run):
+    # the watchdog fires on every rank, rank 0 prints the line with the error in place of the a2 figures, exit code 0
+    r = subprocess.run(cmd + ["--images", "700"], cwd=pkg.ROOT, capture_output=True, text=True, timeout=600,
+                       env=dict(env, MI_BLUR_BENCH_BACKEND="gloo", MI_BLUR_BENCH_DEVICE="0", MI_BLUR_BENCH_A2_LIMIT_S="0.02"))
+    d = _bench_line(r)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "did not complete" in d["extra"]["a2_8192_rowsplit"]["error"]
+    assert d["parity"]["a1_stream"]["images_checked_all_ranks"] == 1400 and "configs[3] only" in d["parity"]["status"]
     # the check bites: a rank that holds the wrong shard fails the whole job, and no line is printed
     r = subprocess.run(cmd + ["--images", "700", "--no-extra"], cwd=pkg.ROOT, capture_output=True, text=True, timeout=600,
                        env=dict(env, MI_BLUR_BENCH_BACKEND="gloo", MI_BLUR_BENCH_DEVICE="0", MI_BLUR_BENCH_FAULT="wrong_shard"))
