@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(const TiledParams p, co
 static_assert(sizeof(TiledParams) <= ZC_PARAM_WORDS * 4 && sizeof(TiledParams) % 4 == 0, "TiledParams must fit a ZcBatch");
 static_assert(sizeof(ZcBatch) / 4 <= 64, "the poller copies a descriptor with one wave-instruction");
 
-template <int C, int R, int RPG>
+template <int C, int R, int RPG, bool RAG>
 __global__ __launch_bounds__(256) void blur_server_kernel(ZcHostCtl *ctl, ZcDevCtl *dev, unsigned seq, unsigned budget, unsigned idle_ticks,
                                                           unsigned long long *trace, int fixed_share)
 {
@@ -755,7 +755,7 @@ __global__ __launch_bounds__(256) void blur_server_kernel(ZcHostCtl *ctl, ZcDevC
         if (threadIdx.x == 0)
             s_ctl[2u + (it & 1u)] = fixed_share ? t + NW : __hip_atomic_fetch_add(&dev->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long t_a = trace ? wall_clock64() : 0ull;
-        tiled_tile<C, R, RPG, true, false, false, false, rowpass_default<R>>(u.p, t - tile_first, count_pending);
+        tiled_tile<C, R, RPG, true, false, RAG, false, rowpass_default<R>>(u.p, t - tile_first, count_pending);
         pending = k % ZC_RING;
         __syncthreads();                              // the next tile is staged into the same LDS; the next ticket is in LDS
         if (tr) { tr[2] += wall_clock64() - t_a; tr[3] = wall_clock64(); }
@@ -1289,17 +1289,22 @@ static int launch_tiled(const LaunchDesc &d, const Tunables &tun, bool ragged = 
 int zc_fill_batch(const LaunchDesc &d, ZcGeometry *geo, ZcBatch *b, unsigned *n_tiles)
 {
     if (!geo || !b || !d.in || !d.out || d.n_images <= 0) return MI_BLUR_ERR_INVALID;
-    if (!tiled_eligible(d.in, d.out, d.width, d.channels)) return MI_BLUR_ERR_UNSUPPORTED;
-    if ((d.in_stride % 16) || (d.out_stride % 16)) return MI_BLUR_ERR_UNSUPPORTED;
     Tunables tun = tunables();
+    const bool aligned = tiled_eligible(d.in, d.out, d.width, d.channels) && !(d.in_stride % 16) && !(d.out_stride % 16);
+    // rows that are not a multiple of 16 bytes / unaligned buffers: the ragged form of the same tile code, dense batches only
+    const long long pitch_b = (long long)d.width * d.channels;
+    const bool dense = (!d.in_stride || d.in_stride == pitch_b * d.band_rows) && (!d.out_stride || d.out_stride == pitch_b * (d.y1 - d.y0));
+    const bool ragged = !aligned && tun.ragged && ragged_eligible(d.width, d.channels) && dense;
+    if (!aligned && !ragged) return MI_BLUR_ERR_UNSUPPORTED;
     tun.debug_copy = 0; tun.debug_xcd_times = 0; tun.xcd_remap = 0;      // tiles are dealt to the workers by the server itself
     TiledParams p{};
     unsigned threads = 0;
     size_t lds = 0;
-    const int rpg = tiled_geometry(d, tun, false, false, 4, p, &threads, &lds);
+    const int rpg = tiled_geometry(d, tun, ragged, false, 4, p, &threads, &lds);
     if (rpg < 0) return rpg;
-    if (geo->threads == 0) { geo->threads = threads; geo->lds = lds; geo->rpg = rpg; geo->channels = d.channels; geo->radius = d.radius; }
-    else if (geo->threads != threads || geo->lds != lds || geo->rpg != rpg || geo->channels != d.channels || geo->radius != d.radius)
+    if (geo->threads == 0) { geo->threads = threads; geo->lds = lds; geo->rpg = rpg; geo->channels = d.channels; geo->radius = d.radius; geo->ragged = ragged ? 1 : 0; }
+    else if (geo->threads != threads || geo->lds != lds || geo->rpg != rpg || geo->channels != d.channels || geo->radius != d.radius ||
+             geo->ragged != (ragged ? 1 : 0))
         return MI_BLUR_ERR_UNSUPPORTED;                                      // another tile shape than the running server's
     memset(b->params, 0, sizeof b->params);
     memcpy(b->params, &p, sizeof p);
@@ -1317,15 +1322,23 @@ int zc_launch_server(const ZcGeometry &geo, ZcHostCtl *ctl, ZcDevCtl *dev, unsig
         hipLaunchKernelGGL(kernel, grid, block, geo.lds, stream, ctl, dev, seq, budget, idle_ticks, trace, fixed_share);
         return hip_status(hipGetLastError());
     };
-    switch (geo.channels * 10 + geo.radius) {
-    case 11: return go(blur_server_kernel<1, 1, 4>);
-    case 12: return go(blur_server_kernel<1, 2, 4>);
-    case 21: return go(blur_server_kernel<2, 1, 4>);
-    case 22: return go(blur_server_kernel<2, 2, 4>);
-    case 31: return go(blur_server_kernel<3, 1, 4>);
-    case 32: return go(blur_server_kernel<3, 2, 4>);
-    case 41: return go(blur_server_kernel<4, 1, 4>);
-    case 42: return go(blur_server_kernel<4, 2, 4>);
+    switch (geo.channels * 100 + geo.radius * 10 + geo.ragged) {
+    case 110: return go(blur_server_kernel<1, 1, 4, false>);
+    case 120: return go(blur_server_kernel<1, 2, 4, false>);
+    case 210: return go(blur_server_kernel<2, 1, 4, false>);
+    case 220: return go(blur_server_kernel<2, 2, 4, false>);
+    case 310: return go(blur_server_kernel<3, 1, 4, false>);
+    case 320: return go(blur_server_kernel<3, 2, 4, false>);
+    case 410: return go(blur_server_kernel<4, 1, 4, false>);
+    case 420: return go(blur_server_kernel<4, 2, 4, false>);
+    case 111: return go(blur_server_kernel<1, 1, 4, true>);
+    case 121: return go(blur_server_kernel<1, 2, 4, true>);
+    case 211: return go(blur_server_kernel<2, 1, 4, true>);
+    case 221: return go(blur_server_kernel<2, 2, 4, true>);
+    case 311: return go(blur_server_kernel<3, 1, 4, true>);
+    case 321: return go(blur_server_kernel<3, 2, 4, true>);
+    case 411: return go(blur_server_kernel<4, 1, 4, true>);
+    case 421: return go(blur_server_kernel<4, 2, 4, true>);
     }
     return MI_BLUR_ERR_INVALID;
 }

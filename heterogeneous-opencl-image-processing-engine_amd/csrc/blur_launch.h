@@ -86,7 +86,7 @@ struct ZcDevCtl {                      // device memory, zeroed when the server 
     unsigned tiles_done[ZC_RING];      // tiles of the batch in this ring slot whose output is in host memory
     ZcBatch batch[ZC_RING];            // device copies of the descriptors
 };
-struct ZcGeometry { unsigned threads; size_t lds; int rpg; int channels, radius; };
+struct ZcGeometry { unsigned threads; size_t lds; int rpg; int channels, radius, ragged; };
 // Tile parameters of one batch (d.in/d.out = DEVICE addresses of the pinned buffers) in the server's geometry; *geo is
 // filled on the first call (geo->threads == 0) and must match on later ones (MI_BLUR_ERR_UNSUPPORTED otherwise).
 int zc_fill_batch(const LaunchDesc &d, ZcGeometry *geo, ZcBatch *b, unsigned *n_tiles);

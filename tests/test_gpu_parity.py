@@ -516,6 +516,40 @@ def test_zero_copy_batch_server(pkg, L, O, torch_cuda, radius):
         ctx.sync()
         assert np.array_equal(np.ctypeslib.as_array((C.c_uint8 * (39 * w * c)).from_address(p_top)).reshape(39, w, c), want[0][:39])
         assert np.array_equal(as_np(outs[0][1]), want[n:2 * n]) and np.array_equal(as_np(outs[0][2]), want[2 * n:3 * n])
+        # frames whose rows are not a multiple of 16 bytes (250x167x3, pitch 750; 33x50x1) go through the server too — the ragged
+        # form of the same tile code — from buffers at odd addresses as well
+        for (rh, rw, rc, rn) in ((167, 250, 3, 7), (50, 33, 1, 5), (64, 1366, 3, 3)):
+            rhost = O.lcg_stream(rn, rh, rw, rc, first_index=900)
+            rwant = O.blur_batch(rhost, radius)
+            rbytes = rhost.nbytes
+            rin, rout = L.mi_blur_host_alloc(rbytes + 64), L.mi_blur_host_alloc(rbytes + 64)
+            for off in (0, 3):
+                C.memmove(rin + off, rhost.ctypes.data, rbytes)
+                C.memset(rout, 0xEE, rbytes + 64)
+                with pkg.Context(0, rw, rh, rc, radius, max_batch=rn, n_slots=2) as rctx:
+                    for _ in range(3):
+                        rctx.submit(rin + off, rout + off, rn)
+                    rctx.sync()
+                    assert L.mi_blur_last_kernel() == b"blur_server_kernel" and L.mi_blur_zero_copy_launches(rctx.h) == 3
+                got = np.ctypeslib.as_array((C.c_uint8 * (rbytes + 64)).from_address(rout))
+                assert np.array_equal(got[off:off + rbytes].reshape(rhost.shape), rwant), (rh, rw, rc, off)
+                assert bool((got[:off] == 0xEE).all()) and bool((got[off + rbytes:] == 0xEE).all())      # nothing written outside
+            L.mi_blur_host_free(rin); L.mi_blur_host_free(rout)
+        # the diagnostics trace: every tile of every batch is accounted for
+        pkg.check(L.mi_blur_set_option(b"zero_copy_trace", 1))
+        try:
+            with pkg.Context(0, w, h, c, radius, max_batch=n, n_slots=2) as tctx:
+                for k in range(6):
+                    tctx.submit(bufs[k % nbuf][0], bufs[k % nbuf][1], n)
+                tctx.sync()
+                nw, head = C.c_int(), C.c_uint()
+                tr = np.zeros(6 * 48 * 5, np.uint64)
+                got_n = L.mi_blur_debug_zc_trace(tctx.h, tr.ctypes.data_as(C.POINTER(C.c_uint64)), 6, C.byref(nw), C.byref(head))
+                assert got_n == 6 and nw.value == 48 and head.value == 6
+                tiles = tr.reshape(6, 48, 5)[:, :, 1]
+                assert (tiles.sum(axis=1) == tiles.sum(axis=1)[0]).all() and tiles.sum(axis=1)[0] > 0      # same tile count per (equal) batch
+        finally:
+            pkg.check(L.mi_blur_set_option(b"zero_copy_trace", 0))
         # destroy with work just submitted: the context drains it, tells its servers to leave and waits for them
         ctxs[1].submit(bufs[3][0], outs[1][3], n)
         for ctx in ctxs:
