@@ -816,14 +816,14 @@ def main() -> None:
             # ---- the batch as the unit of COMPLETION, as the host sees it (per-batch clFinish, heterogeneous_blur.c:538-539):
             # a poll loop on mi_blur_resident_batches_done during `passes` fused passes, each batch stamped with the host
             # time at which a poll first reported it, measured from just before the dispatch call.
-            def batch_completion(passes=24):
+            def batch_completion(passes=24, watch=True):
                 nb = (per_gpu + batch - 1) // batch
                 seen_at = np.full((passes, nb), np.nan)
                 polls, poll_s, disp = 0, 0.0, []
                 for p in range(passes):
                     ctx.sync()
                     t_0 = time.perf_counter()
-                    ctx.resident_run_fused(per_gpu, batch)
+                    ctx.resident_run_fused(per_gpu, batch, watch=watch)
                     seen, deadline = 0, t_0 + 2.0
                     while seen < nb:
                         ta = time.perf_counter()
@@ -843,11 +843,14 @@ def main() -> None:
                         "batches": nb, "passes": passes, "polls_per_pass": round(polls / passes, 1), "poll_us": round(poll_s / polls * 1e6, 1),
                         "pass_wall_us": round(float(np.median(disp)) * 1e6, 1),
                         "how": "median over the passes of the host time (from just before the dispatch call) at which a "
-                               "mi_blur_resident_batches_done poll first reported batch k complete; the poll is a counter "
-                               "read-back on its own stream while the dispatch runs, so resolution = one poll"}
+                               "mi_blur_resident_batches_done poll first reported batch k complete; "
+                               + ("the pass is WATCHED (a one-wave kernel keeps the count in pinned host memory), so a poll is a read "
+                                  "of the host's own memory" if watch else
+                                  "every poll is a counter read-back on its own stream while the dispatch runs, so resolution = one poll")}
 
             batch_completion(3)                                     # poll stream / code paths warm
             completion = batch_completion()
+            completion["by_counter_readback"] = {k: v for k, v in batch_completion(12, watch=False).items() if k != "how"}
 
             # ---- the same pass with the ARCHITECTURAL completion protocol (release-ordered add at agent scope)
             pkg.check(L.mi_blur_set_option(b"fused_release", 1), "set_option")

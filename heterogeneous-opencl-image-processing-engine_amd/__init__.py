@@ -288,8 +288,9 @@ class Context:
         """timed: 0/False none, 1/True every launch, n every n-th launch carries timestamp events."""
         check(lib().mi_blur_resident_run(self.h, n_images, batch, int(timed)), "mi_blur_resident_run")
 
-    def resident_run_fused(self, n_images: int, batch: int, timed: bool = False) -> None:
-        check(lib().mi_blur_resident_run_fused(self.h, n_images, batch, 1 if timed else 0), "mi_blur_resident_run_fused")
+    def resident_run_fused(self, n_images: int, batch: int, timed: bool = False, watch: bool = False) -> None:
+        """watch: a one-wave kernel keeps the pass's progress in pinned host memory (resident_batches_done then costs no HIP call)."""
+        check(lib().mi_blur_resident_run_fused(self.h, n_images, batch, (1 if timed else 0) | (2 if watch else 0)), "mi_blur_resident_run_fused")
 
     def resident_peek(self, pool_index: int, host_out, n_images: int) -> None:
         check(lib().mi_blur_resident_peek(self.h, pool_index, host_out, n_images), "mi_blur_resident_peek")

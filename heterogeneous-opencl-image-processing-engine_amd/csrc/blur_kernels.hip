@@ -542,6 +542,38 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(const TiledParams p, co
     }
 }
 
+// One wave that follows a fused pass for the host: batch n is complete when its eight counters sum to (its blocks) x
+// per_block; the wave then publishes (pass_seq, n + 1) in pinned host memory.  Lanes 0-7 read one counter each.  It ends with
+// the pass (every batch complete) or after ZC_HARD_TICKS — a pass that faulted never completes its counters.
+__global__ __launch_bounds__(64) void fused_watch_kernel(const unsigned *count, unsigned n_batches, unsigned tiles_per_batch, unsigned total_blocks,
+                                                         unsigned per_block, unsigned long long *host_word, unsigned pass_seq)
+{
+    const unsigned lane = threadIdx.x;
+    const unsigned long long t0 = wall_clock64();
+    unsigned n = 0;
+    while (n < n_batches) {
+        const unsigned first = n * tiles_per_batch;
+        const unsigned want = min(tiles_per_batch, total_blocks - first) * per_block;
+        unsigned v = 0;
+        if (lane < 8) v = __hip_atomic_load(&count[8u * n + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+        v = __builtin_amdgcn_readfirstlane(v);
+        if (v == want) {
+            n++;
+            // skip ahead over batches that are complete already before telling the host (one store per advance is plenty)
+            continue;
+        }
+        if (lane == 0) {
+            const unsigned long long cur = ((unsigned long long)pass_seq << 32) | n;
+            if (__hip_atomic_load(host_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != cur)
+                __hip_atomic_store(host_word, cur, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (wall_clock64() - t0 > ZC_HARD_TICKS) return;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    if (lane == 0) __hip_atomic_store(host_word, ((unsigned long long)pass_seq << 32) | n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ----------------------------------------------------------------------------------
 // Zero-copy batch server (see blur_launch.h): batch after batch of pinned host frames through ONE dispatch.
 //
@@ -1341,6 +1373,14 @@ int zc_launch_server(const ZcGeometry &geo, ZcHostCtl *ctl, ZcDevCtl *dev, unsig
     case 421: return go(blur_server_kernel<4, 2, 4, true>);
     }
     return MI_BLUR_ERR_INVALID;
+}
+
+int launch_fused_watch(const unsigned *count, unsigned n_batches, unsigned tiles_per_batch, unsigned total_blocks, unsigned per_block,
+                       unsigned long long *host_word, unsigned pass_seq, hipStream_t stream)
+{
+    if (!count || !host_word || n_batches == 0 || tiles_per_batch == 0) return MI_BLUR_ERR_INVALID;
+    hipLaunchKernelGGL(fused_watch_kernel, dim3(1), dim3(64), 0, stream, count, n_batches, tiles_per_batch, total_blocks, per_block, host_word, pass_seq);
+    return hip_status(hipGetLastError());
 }
 
 int launch_fused(const LaunchDesc &d, const FusedDesc &f)

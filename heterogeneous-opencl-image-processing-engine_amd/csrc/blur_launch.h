@@ -39,6 +39,11 @@ struct FusedDesc {
     const Tunables *tun; bool geometry_only;
 };
 int launch_fused(const LaunchDesc &d, const FusedDesc &f);
+// Watcher of one fused pass (fused_watch_kernel, one wave on a stream of its own): follows the per-batch counters and keeps
+// *host_word (pinned host memory) = (pass_seq << 32) | leading batches complete, so the host reads a batch's completion
+// from its own memory instead of copying the counters back.  Ends when all n_batches are complete (or after a hard limit).
+int launch_fused_watch(const unsigned *count, unsigned n_batches, unsigned tiles_per_batch, unsigned total_blocks, unsigned per_block,
+                       unsigned long long *host_word, unsigned pass_seq, hipStream_t stream);
 
 // Planar (CImg storage: plane c of image i at (i*C + c)*W*H) <-> interleaved repack, layout_kernels.hip.
 int launch_planar_to_interleaved(const uint8_t *src, uint8_t *dst, int width, int height, int channels, int n_images, hipStream_t s);

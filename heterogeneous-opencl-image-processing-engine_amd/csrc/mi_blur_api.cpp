@@ -232,6 +232,10 @@ struct mi_blur_ctx {
     int fused_n = 0, fused_batch = 0;                            // its (n_images, batch): same again = counters keep counting up
     unsigned fused_passes = 0;                                   // passes accumulated in the counters since they were zeroed
     hipStream_t fused_poll = nullptr;
+    hipStream_t fused_watch = nullptr;                           // the watcher's own stream (peeks on fused_poll must not queue behind it)
+    unsigned long long *fused_word = nullptr, *fused_word_dev = nullptr;   // watcher's progress word: pinned host memory + its device address
+    unsigned fused_watch_seq = 0;                                // sequence number of the latest watched pass (0 = none)
+    bool fused_watched = false;                                  // the latest pass has a watcher
     ZcServer *zc = nullptr;                                      // batch server, made on the first submit that can use it
     // CPU device
     std::vector<CpuJob *> cpu_jobs;
@@ -569,7 +573,9 @@ extern "C" void mi_blur_destroy(mi_blur_ctx *c)
         if (c->zc_ref) (void)hipEventDestroy(c->zc_ref);
         if (c->fused_count) (void)hipFree(c->fused_count);
         if (c->fused_host) (void)hipHostFree(c->fused_host);
-        if (c->fused_poll) (void)hipStreamDestroy(c->fused_poll);
+        if (c->fused_poll) { (void)hipStreamSynchronize(c->fused_poll); (void)hipStreamDestroy(c->fused_poll); }
+        if (c->fused_watch) { (void)hipStreamSynchronize(c->fused_watch); (void)hipStreamDestroy(c->fused_watch); }
+        if (c->fused_word) (void)hipHostFree(c->fused_word);
         if (c->pool_in) (void)hipFree(c->pool_in);
         if (c->pool_out) (void)hipFree(c->pool_out);
         (void)hipGetLastError();
@@ -1046,7 +1052,23 @@ extern "C" int mi_blur_resident_run_fused(mi_blur_ctx *c, int n_images, int batc
         c->fused_tpb = tpb; c->fused_wpb = wpb; c->fused_blocks = blocks;
     }
     c->fused_batches = nb;
-    if (timed) {
+    c->fused_watched = false;
+    if (timed & 2) {
+        // a watcher wave keeps (pass, leading batches complete) in pinned host memory for this pass.  Counters that were just
+        // zeroed must BE zero before it looks at them: it runs on its own stream, so wait for the fill.
+        if (c->fused_passes == 1) HIP_TRY(hipStreamSynchronize(s.stream));
+        if (!c->fused_watch) HIP_TRY(hipStreamCreateWithFlags(&c->fused_watch, hipStreamNonBlocking));
+        if (!c->fused_word) {
+            HIP_TRY(hipHostMalloc((void **)&c->fused_word, sizeof(unsigned long long), hipHostMallocDefault));
+            *c->fused_word = 0;
+            HIP_TRY(hipHostGetDevicePointer((void **)&c->fused_word_dev, c->fused_word, 0));
+        }
+        c->fused_watch_seq += 1;
+        rc = launch_fused_watch(c->fused_count, (unsigned)nb, tpb, blocks, wpb * c->fused_passes, c->fused_word_dev, c->fused_watch_seq, c->fused_watch);
+        if (rc) return rc;
+        c->fused_watched = true;
+    }
+    if (timed & 1) {
         if (c->ev_used == c->ev_pool.size()) {
             TimedLaunch t{};
             HIP_TRY(hipEventCreate(&t.s));
@@ -1063,7 +1085,7 @@ extern "C" int mi_blur_resident_run_fused(mi_blur_ctx *c, int n_images, int batc
     c->tm.launches += 1;
     c->tm.images += (uint64_t)n_images;
     c->tm.bytes_alg += 2ull * c->image_bytes * (uint64_t)n_images;
-    if (timed) { c->timed_launches += 1; c->timed_bytes_alg += 2ull * c->image_bytes * (uint64_t)n_images; }
+    if (timed & 1) { c->timed_launches += 1; c->timed_bytes_alg += 2ull * c->image_bytes * (uint64_t)n_images; }
     return MI_BLUR_OK;
 }
 
@@ -1075,6 +1097,10 @@ extern "C" int mi_blur_resident_batches_done(mi_blur_ctx *c)
     if (!c) return MI_BLUR_ERR_INVALID;
     if (c->is_cpu()) return MI_BLUR_ERR_STATE;
     if (!c->fused_count || !c->fused_batches) return 0;       // no fused pass issued (or the last one failed to launch)
+    if (c->fused_watched) {                                   // a watcher wave keeps the answer in host memory: no copy, no HIP call
+        const unsigned long long w = __atomic_load_n(c->fused_word, __ATOMIC_ACQUIRE);
+        return (unsigned)(w >> 32) == c->fused_watch_seq ? (int)(unsigned)(w & 0xffffffffu) : 0;
+    }
     // read the counters on a stream of their own (the pass may still be running on the compute stream)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(c->fused_host, c->fused_count, sizeof(unsigned) * 8 * (size_t)c->fused_batches, hipMemcpyDeviceToHost, c->fused_poll));

@@ -288,7 +288,10 @@ void mi_blur_timed_coverage(mi_blur_ctx *ctx, uint64_t *launches, uint64_t *byte
  * its outputs are in memory.  The batch stays the unit of COMPLETION (mi_blur_resident_batches_done reads the
  * counters and returns how many leading batches have their outputs ready, without waiting for the dispatch, which
  * may still be running) without being the unit of DISPATCH.  n_images <= pool size (one contiguous run of the pool); aligned tiled shapes only
- * (MI_BLUR_ERR_UNSUPPORTED otherwise).  timed != 0: the dispatch carries timestamp events like resident_run.
+ * (MI_BLUR_ERR_UNSUPPORTED otherwise).  `timed` is a bit set: 1 = the dispatch carries timestamp events like resident_run;
+ * 2 = WATCH this pass: a one-wave kernel on a stream of its own follows the counters and keeps "leading batches complete" in
+ * pinned host memory, so that mi_blur_resident_batches_done is a read of the caller's own memory (tens of ns, no HIP call)
+ * instead of a counter read-back (~18 us) — for hosts that consume batch by batch while the pass runs.
  * Asynchronous; follow with mi_blur_sync.
  *
  * Ordering of "counted" against "readable".  Default ("fused_release" 0): outputs are stored write-through

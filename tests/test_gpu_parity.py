@@ -1034,8 +1034,11 @@ def test_fused_stream_random_shapes(pkg, L, O, torch_cuda):
             assert np.array_equal(out, O.blur_batch(O.lcg_stream(n, h, w, c, first_index=case), r)), (case, h, w, c, r, n, batch)
 
 
-def test_fused_stream_batches_are_readable_as_soon_as_counted(pkg, L, O, torch_cuda):
-    """The point of the per-batch counters: while ONE dispatch is still working through a 40 000-image stream, every batch
+@pytest.mark.parametrize("watch", [False, True])
+def test_fused_stream_batches_are_readable_as_soon_as_counted(pkg, L, O, torch_cuda, watch):
+    """watch = True: the pass is WATCHED — a one-wave kernel keeps the number of leading complete batches in pinned host
+    memory, so the poll is a read of the host's own memory (no copy, no HIP call); same property, many more samples.
+    The point of the per-batch counters: while ONE dispatch is still working through a 40 000-image stream, every batch
     the poll reports done must already hold its final bytes when read on another stream (mi_blur_resident_peek does not
     wait for the dispatch).  The output pool is poisoned first (0xEE everywhere: the blur of a constant image), so a batch
     counted in too early would read as poison."""
@@ -1055,7 +1058,7 @@ def test_fused_stream_batches_are_readable_as_soon_as_counted(pkg, L, O, torch_c
         got = np.zeros((batch, h, w, c), np.uint8)
         ctx.resident_peek(n - batch, got.ctypes.data, batch)
         assert (got == 0xEE).all()
-        ctx.resident_run_fused(n, batch)
+        ctx.resident_run_fused(n, batch, watch=watch)
         # capture first (fast: one image per newly reported batch — its LAST image), verify after the dispatch has ended
         captured, last, in_flight = [], 0, 0
         deadline = time.monotonic() + 60.0
@@ -1078,8 +1081,14 @@ def test_fused_stream_batches_are_readable_as_soon_as_counted(pkg, L, O, torch_c
         # The test only means something if samples were taken WHILE the dispatch was running (a 40 000-image pass lasts
         # ~3 ms, a poll + peek ~50 us: tens of samples).  A host so slow that every sample came after the end would make
         # this pass vacuously, so that is a failure, not a pass.
-        print(f"verified {len(captured)} batches, {in_flight} of them read while the dispatch was still running")
+        print(f"watch={watch}: verified {len(captured)} batches, {in_flight} of them read while the dispatch was still running")
         assert in_flight > 0, "no sample was taken mid-dispatch: the early-readability property was not exercised"
+        # a second watched pass right behind an unwatched one, and the count after the end
+        ctx.resident_run_fused(700, batch)
+        ctx.resident_run_fused(700, batch, watch=True)
+        assert ctx.wait_batches(20) == 20
+        ctx.sync()
+        assert ctx.resident_batches_done() == 20
 
 
 def test_fused_stream_release_mode_and_geometry_change(pkg, L, O, torch_cuda):
