@@ -11,6 +11,7 @@
 
 #include <dlfcn.h>
 #include <sched.h>
+#include <time.h>
 
 #include <algorithm>
 #include <chrono>
@@ -103,6 +104,7 @@ extern "C" int mi_blur_set_option(const char *key, int value)
     else if (!strcmp(key, "zero_copy_server")) t.zero_copy_server = value != 0;
     else if (!strcmp(key, "zero_copy_trace")) t.zero_copy_trace = value != 0;
     else if (!strcmp(key, "zero_copy_tickets")) t.zero_copy_tickets = value != 0;
+    else if (!strcmp(key, "zero_copy_spin")) t.zero_copy_spin = value != 0;
     else if (!strcmp(key, "zero_copy_workers")) { if (value < 1 || value > 2048) return MI_BLUR_ERR_INVALID; t.zero_copy_workers = value; }
     else if (!strcmp(key, "zero_copy_idle_us")) { if (value < 10 || value > 100000) return MI_BLUR_ERR_INVALID; t.zero_copy_idle_us = value; }
     else if (!strcmp(key, "zero_copy_budget")) { if (value < 1 || value > (1 << 20)) return MI_BLUR_ERR_INVALID; t.zero_copy_budget = value; }
@@ -435,11 +437,16 @@ static int finish_slot(mi_blur_ctx *c, Slot &s)
         ZcServer &z = *c->zc;
         const unsigned slot = s.zc_index % ZC_RING, want = s.zc_index + 1u;
         const auto t0 = std::chrono::steady_clock::now();
+        // Waiting is a feeder's normal state (a batch takes ~160 us of link time): spin for ~20 us — a batch that is nearly
+        // done should be noticed at once — then sleep in short steps so that the core is free for the threads that build
+        // the next batch; every few ms ask the stream whether the device is still alive.
+        const bool spin_only = tunables().zero_copy_spin != 0;
         for (unsigned spins = 0; __atomic_load_n(&z.ctl->done[slot], __ATOMIC_ACQUIRE) != want; spins++) {
-            if (spins < 4096) { __builtin_ia32_pause(); continue; }
+            if (spins < 2048) { __builtin_ia32_pause(); continue; }
             if (__atomic_load_n(&z.ctl->error, __ATOMIC_ACQUIRE)) return MI_BLUR_ERR_STATE;   // a server gave up on a wait (see blur_server_kernel)
-            std::this_thread::yield();
-            if ((spins & 1023u) == 0) {                          // a faulted device never writes the word: ask the stream now and then
+            if (spin_only) std::this_thread::yield();
+            else { struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
+            if ((spins & 63u) == 0) {                            // a faulted device never writes the word: ask the stream now and then
                 const hipError_t q = hipStreamQuery(z.stream);
                 if (q != hipSuccess && q != hipErrorNotReady) { (void)hipGetLastError(); return MI_BLUR_ERR_HIP_BASE - (int)q; }
                 (void)hipGetLastError();

@@ -97,6 +97,8 @@ const char *mi_blur_last_kernel(void);
  *   "zero_copy_idle_us" 300 (default): a server leaves after this long without a new batch (the next submit starts one)
  *   "zero_copy_budget"  256 (default): ... and after this many batches; the next one, already queued behind it, carries on
  *   "zero_copy_tickets" 1 (default) | 0 = a fixed share of tiles per worker (A/B runs: what a per-batch launch does)
+ *   "zero_copy_spin"    0 (default) = a wait for a batch of the server spins ~20 us, then sleeps in 20 us steps (the core is
+ *                      free for the threads that build the next batch); 1 = spin + yield only
  *   "zero_copy_trace"   0 (default) | 1 = the server's workers stamp their phases (mi_blur_debug_zc_trace)
  *   "zero_copy_events"  1 (default) | 0 = per-batch launches carry no timestamp events (timing experiment; no kernel bucket)
  *   "zero_copy_streams" 4 (default): zero-copy submits of a context alternate over this many of its streams (at most n_slots)
