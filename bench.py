@@ -587,6 +587,50 @@ def main() -> None:
                 return {"error": setup_error or f"RCCL communicator set-up failed on {int(bad.item())} other rank(s)"}
         elif setup_error:
             return {"error": setup_error}
+        # ---- third step form: every rank PULLS its halo rows out of its neighbours' shards with one small copy kernel that reads
+        # the peer's memory directly (mi_blur_halo_pull; IPC handles of the shards travel through an all_gather).  Optional: any
+        # failure to set it up is agreed on by all ranks and the form is left out.  (In the one-GPU rehearsal the "peers" are
+        # other processes on the same device: the IPC plumbing and the kernel are the real ones.)
+        peer_ptrs, pull_note = {}, ""
+        top_src = bottom_src = 0
+        if world > 1:
+            mine = torch.zeros(pkg.PEER_HANDLE_BYTES + 8, dtype=torch.uint8)
+            try:
+                hraw, off = (C.c_uint8 * pkg.PEER_HANDLE_BYTES)(), C.c_uint64()
+                pkg.check(L.mi_blur_peer_export(band.data_ptr(), hraw, C.byref(off)), "peer_export")
+                mine = torch.tensor(list(hraw) + list(int(off.value).to_bytes(8, "little")), dtype=torch.uint8)
+                ok = 1
+            except Exception as e:
+                ok, pull_note = 0, f"rank {rank}: {e}"
+            send = mine.to(dev) if backend == "nccl" else mine
+            gathered = [torch.zeros_like(send) for _ in range(world)]
+            dist.all_gather(gathered, send)
+            if ok:
+                try:
+                    for nb_rank in (rank - 1, rank + 1):
+                        if 0 <= nb_rank < world:
+                            g = gathered[nb_rank].cpu().numpy().tobytes()
+                            hb = (C.c_uint8 * pkg.PEER_HANDLE_BYTES)(*g[:pkg.PEER_HANDLE_BYTES])
+                            noff = int.from_bytes(g[pkg.PEER_HANDLE_BYTES:], "little")
+                            ptr = C.c_void_p()
+                            pkg.check(L.mi_blur_peer_open(hb, noff, C.byref(ptr)), "peer_open")
+                            peer_ptrs[nb_rank] = (ptr.value, noff)
+                    if rank - 1 in peer_ptrs:      # the LAST `radius` owned rows of the shard above
+                        ab = pkg.band_of(H, radius, rank - 1, world)
+                        top_src = peer_ptrs[rank - 1][0] + (ab["halo_top"] + ab["row_end"] - ab["row_begin"] - radius) * pitch
+                    if rank + 1 in peer_ptrs:      # the FIRST `radius` owned rows of the shard below
+                        bottom_src = peer_ptrs[rank + 1][0] + pkg.band_of(H, radius, rank + 1, world)["halo_top"] * pitch
+                except Exception as e:
+                    ok, pull_note = 0, f"rank {rank}: {e}"
+            flag = torch.tensor([0 if ok else 1], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+            if int(flag.item()) > 0:
+                pull_note = pull_note or f"peer set-up failed on {int(flag.item())} other rank(s)"
+                for (ptr_v, noff) in peer_ptrs.values():
+                    L.mi_blur_peer_close(ptr_v, noff)
+                peer_ptrs = {}
+        pull_ok = world > 1 and bool(peer_ptrs) and not pull_note
+
         main_stream = torch.cuda.current_stream()
         stream = main_stream.cuda_stream
 
@@ -617,6 +661,12 @@ def main() -> None:
                 ev_done.record(main_stream)
 
             forms["overlapped"] = step_overlapped
+        if pull_ok:
+            def step_pull():
+                pkg.check(L.mi_blur_halo_pull(band.data_ptr(), top_src or None, bottom_src or None, Wd, c, owned, radius, stream), "halo_pull")
+                blur_rows(ht, ht + owned, 0)
+
+            forms["pull"] = step_pull
 
         # untimed ramp past the ~40 ms clock ramp that follows any idle gap.  A FIXED step count, the same on every rank:
         # each step holds a send/recv pair, so ranks must not decide by their own clocks how many to run.
@@ -629,8 +679,22 @@ def main() -> None:
         want = golden.get("bands8192", {}).get("bands", {}).get(str(world))
         want = want[rank] if want else None
         timed, parity = {}, {"ok": True, "golden": "tests/golden bands8192 (reference kernel)", "band_fnv": {}}
+        halo_rows_host = None
+        if fake_exchange:      # rehearsal: what the (left-out) RCCL exchange would have delivered, kept for re-upload
+            halo_rows_host = (band[:ht * pitch].clone(), band[(ht + owned) * pitch:].clone())
         for fname, fn in forms.items():
             out.zero_()
+            # every form starts from poisoned halo rows, so its OWN exchange is what the band hash proves (rehearsal: the two
+            # RCCL forms get the rows uploaded instead, as their exchange is left out; the pull form is real there as well)
+            if world > 1:
+                if fake_exchange and fname != "pull":
+                    band[:ht * pitch] = halo_rows_host[0]
+                    band[(ht + owned) * pitch:] = halo_rows_host[1]
+                else:
+                    band[:ht * pitch].fill_(0xA5)
+                    band[(ht + owned) * pitch:].fill_(0xA5)
+                torch.cuda.synchronize()
+                barrier_sync()                  # nobody starts pulling / sending before every rank's rows are in place
             if fname == "overlapped":
                 ev_done.record(main_stream)
             for _ in range(W2):
@@ -684,11 +748,18 @@ def main() -> None:
                              device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             decomp["halo_exchange_us_max_over_ranks"], decomp["band_kernel_us_max_over_ranks"] = round(float(t[0]), 2), round(float(t[1]), 2)
+        if world > 1:
+            barrier_sync()                      # no rank closes or frees a shard a neighbour may still be pulling from
+        for (ptr_v, noff) in peer_ptrs.values():
+            L.mi_blur_peer_close(ptr_v, noff)
         if not fake_exchange:
             L.mi_blur_comm_destroy(comm)
         config = {"workload": f"one 8192x8192x3 image per step, 3x3, row-split over {world} GPU(s), RCCL halo exchange [BASELINE configs[4]]",
                   "rows_per_gpu": owned, "halo_bytes_per_neighbour": radius * pitch, "ramp_steps": ramp_steps,
                   "steps_per_form": K2, "step_forms_us": {k: v["step_us"] for k, v in timed.items()}, "quoted_form": quoted,
+                  "rccl_step_us": min(v["step_us"] for k, v in timed.items() if k != "pull"),
+                  "pull_form": ("halo rows pulled out of the neighbours' shards by one copy kernel reading peer memory (IPC-mapped)"
+                                if pull_ok else f"not run: {pull_note or 'one rank'}"),
                   "rccl_ranks": comm_ranks if comm_transport == 1 else 0,
                   "halo_transport": {0: "none (one rank: both image edges clamp)", 1: "RCCL ncclSend/ncclRecv", 2: "peer copies"}[comm_transport],
                   "step_decomposition": decomp}

@@ -31,6 +31,7 @@ DEVICE_CPU = -1
 VARIANT_AUTO, VARIANT_GENERIC, VARIANT_TILED, VARIANT_STREAM, VARIANT_DIRECT = 0, 1, 2, 3, 4
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_NOMEM, ERR_STATE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 UNIQUE_ID_BYTES = 128
+PEER_HANDLE_BYTES = 64
 
 
 def _newer(target: str, sources: list[str]) -> bool:
@@ -170,6 +171,10 @@ def lib() -> C.CDLL:
         "mi_blur_comm_destroy": (None, [vp]),
         "mi_blur_comm_info": (i, [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]),
         "mi_blur_halo_exchange": (i, [vp, u8p, i, i, i, i, vp]),
+        "mi_blur_peer_export": (i, [vp, vp, C.POINTER(C.c_uint64)]),
+        "mi_blur_peer_open": (i, [vp, C.c_uint64, C.POINTER(vp)]),
+        "mi_blur_peer_close": (i, [vp, C.c_uint64]),
+        "mi_blur_halo_pull": (i, [u8p, u8p, u8p, i, i, i, i, vp]),
         "mi_blur_halo_exchange_all": (i, [C.POINTER(vp), i, C.POINTER(vp), i, i, C.POINTER(i), i, C.POINTER(vp)]),
     }
     for name, (res, args) in sig.items():

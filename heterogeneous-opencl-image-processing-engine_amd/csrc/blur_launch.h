@@ -48,6 +48,8 @@ int launch_fused_watch(const unsigned *count, unsigned n_batches, unsigned tiles
 // Planar (CImg storage: plane c of image i at (i*C + c)*W*H) <-> interleaved repack, layout_kernels.hip.
 int launch_planar_to_interleaved(const uint8_t *src, uint8_t *dst, int width, int height, int channels, int n_images, hipStream_t s);
 int launch_interleaved_to_planar(const uint8_t *src, uint8_t *dst, int width, int height, int channels, int n_images, hipStream_t s);
+// Halo pull: copy `bytes` bytes from each non-null (peer) source into the matching halo destination, one launch.
+int launch_halo_pull(const uint8_t *top_src, uint8_t *top_dst, const uint8_t *bottom_src, uint8_t *bottom_dst, size_t bytes, hipStream_t stream);
 
 // ----------------------------------------------------------------------------------------------------------------
 // Zero-copy batch server (blur_server_kernel): ONE long-lived dispatch takes batch after batch of pinned host frames from a

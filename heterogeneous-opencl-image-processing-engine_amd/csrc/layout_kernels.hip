@@ -161,6 +161,34 @@ static int repack(const uint8_t *src, uint8_t *dst, int width, int height, int c
     return hip_status(hipGetLastError());
 }
 
+// Halo pull (mi_blur_halo_pull): up to two runs of `bytes` bytes, each from a (peer) source into this rank's halo rows.
+// 16 bytes per thread where both ends are 16-byte aligned, bytes otherwise; blockIdx.y picks the run.
+struct PullParams { const uint8_t *src[2]; uint8_t *dst[2]; unsigned long long bytes; };
+
+__global__ __launch_bounds__(256) void halo_pull_kernel(const PullParams p)
+{
+    const uint8_t *s = p.src[blockIdx.y];
+    uint8_t *d = p.dst[blockIdx.y];
+    if (!s) return;
+    const unsigned long long i = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 16ull;
+    if (i >= p.bytes) return;
+    if (((uintptr_t)s | (uintptr_t)d) % 16 == 0 && i + 16 <= p.bytes) {
+        *reinterpret_cast<u32x4 *>(d + i) = *reinterpret_cast<const u32x4 *>(s + i);
+    } else {
+        for (unsigned long long k = i; k < i + 16 && k < p.bytes; k++) d[k] = s[k];
+    }
+}
+
+int launch_halo_pull(const uint8_t *top_src, uint8_t *top_dst, const uint8_t *bottom_src, uint8_t *bottom_dst, size_t bytes, hipStream_t stream)
+{
+    if (bytes == 0 || (!top_src && !bottom_src)) return MI_BLUR_OK;
+    PullParams p{};
+    p.src[0] = top_src; p.dst[0] = top_dst; p.src[1] = bottom_src; p.dst[1] = bottom_dst; p.bytes = bytes;
+    const unsigned blocks = (unsigned)((bytes + 16 * 256 - 1) / (16 * 256));
+    hipLaunchKernelGGL(halo_pull_kernel, dim3(blocks, 2), dim3(256), 0, stream, p);
+    return hip_status(hipGetLastError());
+}
+
 int launch_planar_to_interleaved(const uint8_t *src, uint8_t *dst, int w, int h, int c, int n, hipStream_t s) { return repack<true>(src, dst, w, h, c, n, s); }
 int launch_interleaved_to_planar(const uint8_t *src, uint8_t *dst, int w, int h, int c, int n, hipStream_t s) { return repack<false>(src, dst, w, h, c, n, s); }
 

@@ -1471,6 +1471,56 @@ extern "C" int mi_blur_halo_exchange(mi_blur_comm *c, uint8_t *d_band, int width
     return rc ? rc : rc2;
 }
 
+// ----------------------------------------------------------------------------------
+// Halo pull: a rank reads its halo rows straight out of its neighbours' shards (peer memory) with one small kernel.
+// ----------------------------------------------------------------------------------
+static_assert(sizeof(hipIpcMemHandle_t) == MI_BLUR_PEER_HANDLE_BYTES, "hipIpcMemHandle_t size");
+
+extern "C" int mi_blur_peer_export(const void *d_ptr, uint8_t handle[MI_BLUR_PEER_HANDLE_BYTES], uint64_t *offset)
+{
+    if (!d_ptr || !handle || !offset) return MI_BLUR_ERR_INVALID;
+    if (mi_blur_device_count() <= 0) return MI_BLUR_ERR_NO_DEVICE;
+    // the handle names a whole allocation; callers (torch's caching allocator, for one) hand out pieces of bigger ones
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    HIP_TRY(hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)d_ptr));
+    hipIpcMemHandle_t h;
+    HIP_TRY(hipIpcGetMemHandle(&h, base));
+    memcpy(handle, &h, sizeof h);
+    *offset = (uint64_t)((const uint8_t *)d_ptr - (const uint8_t *)base);
+    return MI_BLUR_OK;
+}
+
+extern "C" int mi_blur_peer_open(const uint8_t handle[MI_BLUR_PEER_HANDLE_BYTES], uint64_t offset, void **d_ptr)
+{
+    if (!handle || !d_ptr) return MI_BLUR_ERR_INVALID;
+    *d_ptr = nullptr;
+    if (mi_blur_device_count() <= 0) return MI_BLUR_ERR_NO_DEVICE;
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof h);
+    void *base = nullptr;
+    HIP_TRY(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess));
+    *d_ptr = (uint8_t *)base + offset;
+    return MI_BLUR_OK;
+}
+
+extern "C" int mi_blur_peer_close(void *d_ptr, uint64_t offset)
+{
+    if (!d_ptr) return MI_BLUR_OK;
+    HIP_TRY(hipIpcCloseMemHandle((uint8_t *)d_ptr - offset));
+    return MI_BLUR_OK;
+}
+
+extern "C" int mi_blur_halo_pull(uint8_t *d_band, const uint8_t *top_src, const uint8_t *bottom_src, int width, int channels,
+                                 int owned_rows, int radius, void *stream)
+{
+    if (!d_band || width <= 0 || channels <= 0 || radius < 1 || owned_rows < radius) return MI_BLUR_ERR_INVALID;
+    if (mi_blur_device_count() <= 0) return MI_BLUR_ERR_NO_DEVICE;
+    const size_t pitch = (size_t)width * channels, n = pitch * (size_t)radius;
+    const size_t top = top_src ? (size_t)radius : 0;                      // layout: [halo_top rows][owned rows][halo_bottom rows]
+    return launch_halo_pull(top_src, d_band, bottom_src, d_band + (top + (size_t)owned_rows) * pitch, n, (hipStream_t)stream);
+}
+
 // All ranks of a single-process communicator set in ONE RCCL group (one host thread
 // driving G GPUs must not block on rank 0's group before enqueuing rank 1's).
 extern "C" int mi_blur_halo_exchange_all(mi_blur_comm **comms, int n, uint8_t **d_bands, int width, int channels,

@@ -389,6 +389,23 @@ int mi_blur_comm_info(mi_blur_comm *comm, int *n_ranks, int *rank, int *transpor
 int mi_blur_halo_exchange(mi_blur_comm *comm, uint8_t *d_band, int width, int channels,
                           int owned_rows, int radius, void *stream);
 
+/* A second way to fill the halo rows, for hosts that can hand device pointers between ranks: each rank PULLS its halo rows
+ * out of its neighbours' shards with a small copy kernel that reads the peer's memory directly (over xGMI between GPUs) —
+ * no collective library in the step, one ~4 us launch instead of a send/recv pair.  One process per GPU: every rank exports
+ * its shard (mi_blur_peer_export: a 64-byte IPC handle of the allocation + the shard's offset inside it), the handles travel
+ * by any means (bench.py: an all_gather), each rank opens its neighbours' (mi_blur_peer_open) and from then on calls
+ * mi_blur_halo_pull(d_band, top_src, bottom_src, ...) per step with top_src = address of the LAST `radius` owned rows of rank
+ * g-1's shard and bottom_src = the FIRST `radius` owned rows of rank g+1's (NULL where there is no neighbour).  A rank may
+ * only pull rows its neighbour is not writing at the time: for the repeated blur of one resident image (BASELINE configs[4])
+ * the owned rows never change; an iterated blur needs a cross-rank barrier per step (not provided here).
+ * mi_blur_peer_close when done, before the owner frees the shard. */
+#define MI_BLUR_PEER_HANDLE_BYTES 64
+int mi_blur_peer_export(const void *d_ptr, uint8_t handle[MI_BLUR_PEER_HANDLE_BYTES], uint64_t *offset);
+int mi_blur_peer_open(const uint8_t handle[MI_BLUR_PEER_HANDLE_BYTES], uint64_t offset, void **d_ptr);
+int mi_blur_peer_close(void *d_ptr, uint64_t offset);
+int mi_blur_halo_pull(uint8_t *d_band, const uint8_t *top_src, const uint8_t *bottom_src, int width, int channels,
+                      int owned_rows, int radius, void *stream);
+
 /* Single-process form: all n ranks of a mi_blur_comm_init_all set in one RCCL group. */
 int mi_blur_halo_exchange_all(mi_blur_comm **comms, int n, uint8_t **d_bands, int width, int channels,
                               const int *owned_rows, int radius, void **streams);

@@ -370,10 +370,12 @@ def test_bench_spawns_its_own_ranks(pkg):
     assert d["parity"]["status"] == "ok" and d["parity"]["a1_stream"] == dict(d["parity"]["a1_stream"], images_checked_all_ranks=1400, mismatches=0)
     a2 = d["extra"]["a2_8192_rowsplit"]
     assert "configs[4]" in a2["workload"] and a2["rows_per_gpu"] == 4096 and a2["scaling"] == "strong" and a2["img_s"] > 0
-    assert set(a2["step_forms_us"]) == {"plain", "overlapped"} and a2["quoted_form"] in a2["step_forms_us"] and a2["steps_per_form"] == 200
-    assert a2["rccl_ranks"] == 0 and "rehearsal" in a2                    # exchange leg left out on a one-GPU box, and the line says so
+    assert set(a2["step_forms_us"]) == {"plain", "overlapped", "pull"} and a2["quoted_form"] in a2["step_forms_us"] and a2["steps_per_form"] == 200
+    assert a2["rccl_ranks"] == 0 and "rehearsal" in a2                    # RCCL exchange leg left out on a one-GPU box, and the line says so
+    assert a2["rccl_step_us"] == min(a2["step_forms_us"]["plain"], a2["step_forms_us"]["overlapped"]) and "pulled out of the neighbours" in a2["pull_form"]
+    # the pull form is REAL even here (the peer is another process on the same device): it starts from poisoned halo rows
     pa = d["parity"]["a2_8192_rowsplit"]
-    assert pa["ok"] and set(pa["band_fnv"]) == {"plain", "overlapped"} and pa["band_fnv"]["plain"] == pa["band_fnv"]["overlapped"] == "0d04249de0140100"
+    assert pa["ok"] and set(pa["band_fnv"]) == {"plain", "overlapped", "pull"} and set(pa["band_fnv"].values()) == {"0d04249de0140100"}
     # the configs[3] line survives a configs[4] leg that never completes (a stuck exchange on the first real multi-GPU run):
     # the watchdog fires on every rank, rank 0 prints the line with the error in place of the a2 figures, exit code 0
     r = subprocess.run(cmd + ["--images", "700"], cwd=pkg.ROOT, capture_output=True, text=True, timeout=600,

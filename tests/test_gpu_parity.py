@@ -564,6 +564,46 @@ def test_zero_copy_batch_server(pkg, L, O, torch_cuda, radius):
             L.mi_blur_host_free(pi); L.mi_blur_host_free(po)
 
 
+@pytest.mark.parametrize("radius", [1, 2])
+def test_halo_pull_fills_the_halo_rows(pkg, L, O, torch_cuda, radius):
+    """mi_blur_halo_pull: a rank's halo rows copied straight out of its neighbours' shards by one small kernel (here the
+    "peers" are other tensors on the same device; across processes the pointers come from mi_blur_peer_open — rehearsed by
+    tests/test_cli.py::test_bench_spawns_its_own_ranks).  Three row shards of one image, pulled halos, band blur == whole-image
+    blur; aligned rows and rows that are not a multiple of 16 bytes; first / middle / last shard (one or two neighbours)."""
+    torch = torch_cuda
+    for (h, w, c) in ((96, 320, 3), (61, 250, 3), (48, 33, 1)):
+        img = O.lcg_image(h, w, c)
+        want = O.blur(img, radius)
+        pitch = w * c
+        G = 3
+        bands = [pkg.band_of(h, radius, g, G) for g in range(G)]
+        bufs = []
+        for b in bands:                                # every shard: [halo_top poison][owned rows][halo_bottom poison]
+            owned = b["row_end"] - b["row_begin"]
+            t = torch.full(((b["halo_top"] + owned + b["halo_bottom"]) * pitch,), 0xA5, dtype=torch.uint8, device="cuda")
+            t[b["halo_top"] * pitch:(b["halo_top"] + owned) * pitch] = torch.from_numpy(img[b["row_begin"]:b["row_end"]].reshape(-1)).cuda()
+            bufs.append(t)
+        got = np.zeros_like(img)
+        for g, b in enumerate(bands):
+            owned = b["row_end"] - b["row_begin"]
+            top_src = bottom_src = None
+            if g > 0:
+                a = bands[g - 1]
+                top_src = bufs[g - 1].data_ptr() + (a["halo_top"] + a["row_end"] - a["row_begin"] - radius) * pitch
+            if g < G - 1:
+                bottom_src = bufs[g + 1].data_ptr() + bands[g + 1]["halo_top"] * pitch
+            pkg.check(L.mi_blur_halo_pull(bufs[g].data_ptr(), top_src, bottom_src, w, c, owned, radius, None), "halo_pull")
+            rows = b["halo_top"] + owned + b["halo_bottom"]
+            out = torch.zeros(owned * pitch, dtype=torch.uint8, device="cuda")
+            pkg.check(L.mi_blur_enqueue_band(bufs[g].data_ptr(), out.data_ptr(), w, rows, c, radius, b["halo_top"], b["halo_top"] + owned, None))
+            torch.cuda.synchronize()
+            got[b["row_begin"]:b["row_end"]] = out.cpu().numpy().reshape(owned, w, c)
+        assert np.array_equal(got, want), (h, w, c)
+    assert L.mi_blur_halo_pull(None, None, None, 16, 3, 8, 1, None) == pkg.ERR_INVALID
+    t = torch.zeros(1024, dtype=torch.uint8, device="cuda")
+    assert L.mi_blur_halo_pull(t.data_ptr(), None, None, 16, 3, 8, 1, None) == pkg.OK          # no neighbour: nothing to do
+
+
 def test_submit_bands_strided_batch(pkg, L, O, torch_cuda):
     """Approach 2 for a whole batch (mi_blur_submit_bands): the same rows of every image of a contiguous batch
     stream, gathered by one 2-D DMA (pinned memory) or through the pinned staging slot (pageable memory)."""

@@ -38,6 +38,19 @@ def main():
                 us = sorted(ts)[2]
                 cells.append(f"rows/thread {rpt}: {us:6.2f} us ({2 * owned * pitch / us / 1e3:5.0f} GB/s)")
             pkg.check(L.mi_blur_set_option(b"rows_per_thread", 0))
+            if N > 1:      # the step with the halo rows pulled out of a neighbouring shard first (same device here: the kernel cost only)
+                other = torch.empty(rows * pitch, dtype=torch.uint8, device="cuda"); other.random_(0, 256)
+                src_top, src_bot = other.data_ptr() + owned * pitch, other.data_ptr() + ht * pitch
+                ts = []
+                for rep in range(5):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(100):
+                        pkg.check(L.mi_blur_halo_pull(band.data_ptr(), src_top, src_bot, W, c, owned, radius, stream))
+                        pkg.check(L.mi_blur_enqueue_band(band.data_ptr(), out.data_ptr(), W, rows, c, radius, ht, ht + owned, stream))
+                    e1.record(); torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1) * 1e3 / 100)
+                cells.append(f"pull + band: {sorted(ts)[2]:6.2f} us")
             print(f"radius {radius}  N={N} band of {owned} rows: " + "   ".join(cells), flush=True)
             del band, out
 
