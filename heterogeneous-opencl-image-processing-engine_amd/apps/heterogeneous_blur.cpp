@@ -452,6 +452,12 @@ int main(int argc, char **argv)
             printf("   Host link: %.1f GB/s in, %.1f GB/s out (sum over GPUs)\n",
                    (double)total_images_gpu * image_size / (tgpu.in_ms / 1000.0) / 1e9 * G,
                    (double)total_images_gpu * image_size / (tgpu.out_ms / 1000.0) / 1e9 * G);
+        else if (!opt.resident && tgpu.kernel_ms > 0)
+            // pinned batch buffers blurred in place over PCIe (batch server): the kernel bucket IS the transfer, the bound is
+            // the host link, not HBM — 56.4 GB/s is the measured one-way DMA rate of this link (profiles/r01_pcie_probe.txt)
+            printf("   Host link (buffers blurred in place over PCIe: link-bound, not HBM-bound): %.1f GB/s each way per GPU = %.0f%% of the 56.4 GB/s one-way DMA rate, both directions at once\n",
+                   (double)total_images_gpu * image_size / (tgpu.kernel_ms / 1000.0) / 1e9,
+                   (double)total_images_gpu * image_size / (tgpu.kernel_ms / 1000.0) / 1e9 / 56.4 * 100.0);
         printf("\n");
     }
     if (!opt.csv.empty())

@@ -11,7 +11,7 @@ for cmd in "heterogeneous_blur cpu 0.5 35 --size 256x256" "heterogeneous_blur cp
            "heterogeneous_blur gpu 1.0 35 --size 256x256 --resident" "heterogeneous_blur gpu 1.0 35 --size 256x256 --images 50000 --resident --fused" "heterogeneous_blur gpu 1.0 35 --size 1920x1080 --ksize 5 --images 500" \
            "split_image_blur 0.837 35 --size 320x240" "split_image_blur --resident --gpus 1 --size 8192x8192 --iters 50"; do
   echo; echo "\$ $cmd"
-  $A/$cmd 2>&1 | grep -E "Mode:|CPU device|Auto-cal|wall-clock|processed|Transfer|Kernel exec|imbalance|Images per second|Megapixels|Recommended|Launches|Kernel-only|Host link|EQUALS|per image|Algorithmic bandwidth"
+  $A/$cmd 2>&1 | grep -E "Mode:|CPU device|Auto-cal|wall-clock|processed|Transfer|Kernel exec|imbalance|Images per second|Megapixels|Recommended|Launches|Kernel-only|Per-dispatch|Host link|EQUALS|per image|Algorithmic bandwidth"
 done
 } > $OUT 2>&1
 tail -5 $OUT
