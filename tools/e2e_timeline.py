@@ -28,11 +28,13 @@ def main():
     for k, v in opts:
         if k == "arena":
             arena_mib = int(v)
+        elif k == "radius":
+            pass
         elif k == "shape":                                 # shape=WxH (probe's own): e.g. a frame whose rows are not a multiple of 16 bytes
             shape = tuple(int(x) for x in v.split("x"))
         else:
             pkg.check(L.mi_blur_set_option(k.encode(), int(v)), k)
-    w, h, c, r = shape[0], shape[1], 3, 1
+    w, h, c, r = shape[0], shape[1], 3, int(dict(opts).get("radius", 1))
     nbytes = nb * h * w * c
     arena = None
     if arena_mib:       # ONE pinned allocation of at least arena MiB, the batch buffers carved out of it at 2 MiB-aligned offsets
