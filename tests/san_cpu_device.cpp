@@ -25,7 +25,16 @@ int main()
         mi_blur::cpu_blur_batch(in, bo, W, H, C, R, n, y0, y1, nt, 0, 0);
         for (int i = 0; i < n; i++)
             if (memcmp(bo + (size_t)i * (y1 - y0) * W * C, want + i * isz + (size_t)y0 * W * C, (size_t)(y1 - y0) * W * C)) { printf("BAND MISMATCH\n"); return 1; }
-        free(bo); free(in); free(out); free(want); cases++;
+        free(bo);
+        // planar <-> interleaved repack of the frame path (mi_blur_submit_planar on the CPU device): round trip + spot check
+        uint8_t *pl = (uint8_t *)malloc(isz * n), *back = (uint8_t *)malloc(isz * n);
+        mi_blur::cpu_repack(in, pl, W, H, C, n, false, nt);             // interleaved -> planar
+        mi_blur::cpu_repack(pl, back, W, H, C, n, true, nt);             // planar -> interleaved
+        if (memcmp(back, in, isz * n)) { printf("REPACK ROUND TRIP MISMATCH\n"); return 1; }
+        const int px = rnd(W * H), ch = rnd(C), im = rnd(n);
+        if (pl[(size_t)im * isz + (size_t)ch * W * H + px] != in[(size_t)im * isz + (size_t)px * C + ch]) { printf("REPACK LAYOUT MISMATCH\n"); return 1; }
+        free(pl); free(back);
+        free(in); free(out); free(want); cases++;
     }
     printf("%d random cases clean\n", cases);
     return 0;
