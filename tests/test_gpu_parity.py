@@ -494,6 +494,34 @@ def test_zero_copy_batch_server(pkg, L, O, torch_cuda, radius):
                 for key, v in (("zero_copy_idle_us", 300), ("zero_copy_budget", 256), ("zero_copy_workers", 48)):
                     pkg.check(L.mi_blur_set_option(key.encode(), v))
 
+        # a long stream (the descriptor ring, 64 entries, comes round several times; a budget of 7 rolls the server over in
+        # mid-stream; random batch sizes): every batch is checked and its output poisoned again BEFORE its buffers are reused,
+        # so a batch that was skipped, or done twice into the wrong buffer, cannot hide behind an earlier one's bytes
+        pkg.check(L.mi_blur_set_option(b"zero_copy_budget", 7))
+        try:
+            rng = np.random.default_rng(5 + radius)
+            with pkg.Context(0, w, h, c, radius, max_batch=n, n_slots=nbuf) as ctx:
+                sizes = [n] * nbuf
+                for (_pi, po) in bufs:
+                    C.memset(po, 0xEE, nbytes)
+                for i in range(230):
+                    k = i % nbuf
+                    if i >= nbuf:
+                        ctx.wait_oldest()                                      # batch i - nbuf: the one that used these buffers
+                        assert np.array_equal(as_np(bufs[k][1])[:sizes[k]], want[k * n:k * n + sizes[k]]), i
+                        assert bool((as_np(bufs[k][1])[sizes[k]:] == 0xEE).all()), i
+                        C.memset(bufs[k][1], 0xEE, nbytes)
+                    sizes[k] = int(rng.integers(1, n + 1))
+                    if i % 37 == 36:
+                        time.sleep(0.001)                                      # now and then the producer stalls past the idle time-out
+                    ctx.submit(bufs[k][0], bufs[k][1], sizes[k])
+                ctx.sync()
+                for k in range(nbuf):
+                    assert np.array_equal(as_np(bufs[k][1])[:sizes[k]], want[k * n:k * n + sizes[k]]), k
+                assert L.mi_blur_zero_copy_launches(ctx.h) == 230
+        finally:
+            pkg.check(L.mi_blur_set_option(b"zero_copy_budget", 256))
+
         # three contexts side by side (each has its own server), fed in turn
         ctxs = [pkg.Context(0, w, h, c, radius, max_batch=n, n_slots=2) for _ in range(3)]
         outs = [[L.mi_blur_host_alloc(nbytes) for _ in range(nbuf)] for _ in ctxs]
