@@ -132,6 +132,8 @@ def lib() -> C.CDLL:
         "mi_blur_destroy": (None, [vp]),
         "mi_blur_host_alloc": (vp, [C.c_size_t]),
         "mi_blur_host_free": (None, [vp]),
+        "mi_blur_host_register": (i, [vp, C.c_size_t]),
+        "mi_blur_host_unregister": (i, [vp]),
         "mi_blur_device_cpulist": (i, [i, C.c_char_p, C.c_size_t, C.POINTER(i)]),
         "mi_blur_bind_thread_to_device": (i, [i]),
         "mi_blur_host_alloc_on": (vp, [i, C.c_size_t]),

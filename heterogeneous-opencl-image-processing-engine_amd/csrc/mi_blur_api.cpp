@@ -272,6 +272,22 @@ extern "C" void *mi_blur_host_alloc(size_t bytes)
     return malloc(bytes);   // CPU-only operation: ordinary memory
 }
 
+extern "C" int mi_blur_host_register(void *p, size_t bytes)
+{
+    if (!p || bytes == 0) return MI_BLUR_ERR_INVALID;
+    if (mi_blur_device_count() <= 0) return MI_BLUR_OK;
+    HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped));
+    return MI_BLUR_OK;
+}
+
+extern "C" int mi_blur_host_unregister(void *p)
+{
+    if (!p) return MI_BLUR_ERR_INVALID;
+    if (mi_blur_device_count() <= 0) return MI_BLUR_OK;
+    HIP_TRY(hipHostUnregister(p));
+    return MI_BLUR_OK;
+}
+
 extern "C" void mi_blur_host_free(void *p)
 {
     if (!p) return;

@@ -183,6 +183,13 @@ void mi_blur_destroy(mi_blur_ctx *ctx);
 void *mi_blur_host_alloc(size_t bytes);
 void mi_blur_host_free(void *p);
 
+/* Pin the caller's OWN buffers in place (hipHostRegister): a host that keeps its malloc'd batch buffers
+ * (heterogeneous_blur.c:431-432, hoisted out of the batch loop) gets the in-place path of mi_blur_host_alloc memory without
+ * changing its allocator.  The range must stay allocated until mi_blur_host_unregister; registering costs ~1 ms per 10 MB,
+ * so do it once, not per batch.  Without a GPU both calls succeed and do nothing. */
+int mi_blur_host_register(void *p, size_t bytes);
+int mi_blur_host_unregister(void *p);
+
 /* NUMA placement of per-GPU host work.  The reference drives both of its devices from one host thread of a one-socket
  * desktop (heterogeneous_blur.c:482-539); an 8-GPU node has two sockets with four GPUs each, and a feeder thread, a
  * batch-building memcpy (:439-442) or a pinned batch buffer on the other socket puts every byte of the stream on the

@@ -62,6 +62,8 @@ def test_numa_placement_calls_without_a_gpu(pkg, L):
     p = L.mi_blur_host_alloc_on(0, 4096)
     assert p
     C.memset(p, 7, 4096)
+    assert L.mi_blur_host_register(p, 4096) == pkg.OK and L.mi_blur_host_unregister(p) == pkg.OK      # no GPU: nothing to pin
+    assert L.mi_blur_host_register(None, 4096) == pkg.ERR_INVALID
     L.mi_blur_host_free(p)
 
 

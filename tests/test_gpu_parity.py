@@ -392,6 +392,18 @@ def test_context_submit_pageable_and_pinned(pkg, L, O, torch_cuda):
         finally:
             pkg.check(L.mi_blur_set_option(b"zero_copy", 1))
         L.mi_blur_host_free(p_in); L.mi_blur_host_free(p_out)
+        # the caller's own (malloc'd) buffers registered in place: the same in-place path as mi_blur_host_alloc memory
+        own_in, own_out = host.copy(), np.zeros_like(host)
+        pkg.check(L.mi_blur_host_register(own_in.ctypes.data, nbytes)); pkg.check(L.mi_blur_host_register(own_out.ctypes.data, nbytes))
+        before = L.mi_blur_zero_copy_launches(ctx.h)
+        ctx.submit(own_in.ctypes.data, own_out.ctypes.data, n)
+        ctx.sync()
+        assert L.mi_blur_zero_copy_launches(ctx.h) - before == 1 and np.array_equal(own_out, want)
+        pkg.check(L.mi_blur_host_unregister(own_in.ctypes.data)); pkg.check(L.mi_blur_host_unregister(own_out.ctypes.data))
+        own_out[:] = 0
+        ctx.submit(own_in.ctypes.data, own_out.ctypes.data, n)                  # unregistered again: staged, same bytes
+        ctx.sync()
+        assert L.mi_blur_zero_copy_launches(ctx.h) - before == 1 and np.array_equal(own_out, want)
         # Approach-2 bands through the context
         one = np.ascontiguousarray(host[0]); split = 39
         top, bot = np.zeros((split, w, c), np.uint8), np.zeros((h - split, w, c), np.uint8)

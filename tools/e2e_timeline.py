@@ -28,7 +28,7 @@ def main():
     for k, v in opts:
         if k == "arena":
             arena_mib = int(v)
-        elif k == "radius":
+        elif k in ("radius", "pageable"):                   # pageable=1: ordinary (malloc'd) caller buffers, the reference's own kind
             pass
         elif k == "shape":                                 # shape=WxH (probe's own): e.g. a frame whose rows are not a multiple of 16 bytes
             shape = tuple(int(x) for x in v.split("x"))
@@ -43,6 +43,13 @@ def main():
         arena = L.mi_blur_host_alloc(total)
         base = (arena + (2 << 20) - 1) // (2 << 20) * (2 << 20)
         bufs = [(base + (2 * i) * step, base + (2 * i + 1) * step) for i in range(ns)]
+    elif int(dict(opts).get("pageable", 0)):
+        import numpy as np
+        keep = [(np.zeros(nbytes, np.uint8), np.zeros(nbytes, np.uint8)) for _ in range(ns)]
+        bufs = [(a.ctypes.data, b.ctypes.data) for a, b in keep]
+        if int(dict(opts).get("pageable", 0)) == 2:           # pageable=2: the same malloc'd buffers, registered in place once
+            for (pi, po) in bufs:
+                pkg.check(L.mi_blur_host_register(pi, nbytes)); pkg.check(L.mi_blur_host_register(po, nbytes))
     else:
         bufs = [(L.mi_blur_host_alloc(nbytes), L.mi_blur_host_alloc(nbytes)) for _ in range(ns)]
     for (pi, _po) in bufs:
@@ -72,6 +79,8 @@ def main():
     ctx.close()
     if arena:
         L.mi_blur_host_free(arena)
+    elif int(dict(opts).get("pageable", 0)):
+        pass
     else:
         for (pi, po) in bufs:
             L.mi_blur_host_free(pi)
