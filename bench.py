@@ -844,6 +844,13 @@ def main() -> None:
         units = per_gpu * world * K
         value = units / elapsed
         scaling = "weak"
+        per_rank = None
+        if world > 1:      # every rank's own rate and dispatch time: a straggler (a GPU on a busy socket, a slow link) shows here
+            mine = torch.tensor([per_gpu * K / local, tm["kernel_ms"] * 1e3 / max(ctx.timed_coverage()[0], 1)], dtype=torch.float64,
+                                device=dev if backend == "nccl" else "cpu")
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank = {"img_s": [round(float(t[0]), 0) for t in allr], "avg_launch_us": [round(float(t[1]), 2) for t in allr]}
         launches, (timed_n, timed_bytes) = tm["launches"], ctx.timed_coverage()
         if tm["kernel_ms"] > 0 and timed_n > 0:
             bytes_per_launch = timed_bytes / timed_n
@@ -860,6 +867,8 @@ def main() -> None:
                   "reference_published_on": "320x240x3, i7-12700 + UHD 770 (CPU+iGPU together)"}
         if fused:
             config["batches_counted_in_last_pass"] = ctx.resident_batches_done()
+        if per_rank:
+            config["per_rank"] = per_rank
 
         # ---- parity (after the clock has stopped): EVERY output image of this rank's shard is downloaded, hashed and compared
         # with the unmodified reference kernel's hash of the same image of the stream (tests/golden/stream50k_image_fnv.npy).

@@ -365,6 +365,7 @@ def test_bench_spawns_its_own_ranks(pkg):
     d = _bench_line(r)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d
     assert d["config"]["images_per_gpu_per_step"] == 700 and d["config"]["images_per_step"] == 1400 and d["roofline"]["bound"] == "hbm"
+    assert len(d["config"]["per_rank"]["img_s"]) == 2 and min(d["config"]["per_rank"]["img_s"]) > 0 and d["value"] <= sum(d["config"]["per_rank"]["img_s"]) * 1.001
     # ONE invocation carries BOTH multi-GPU configs and has checked the pixels of both against the reference kernel's hashes:
     # every image of both shards (configs[3]) and each rank's band of the 8192^2 output in both step forms (configs[4])
     assert d["parity"]["status"] == "ok" and d["parity"]["a1_stream"] == dict(d["parity"]["a1_stream"], images_checked_all_ranks=1400, mismatches=0)
