@@ -705,7 +705,8 @@ static int submit_common(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_o
         // images/s end to end.  Each zero-copy launch keeps only "zero_copy_blocks" workgroups resident (they loop over the
         // tiles) and consecutive launches alternate over up to "zero_copy_streams" of the context's streams, so that reads
         // of one tile and writes of another keep both directions of the link busy (profiles/r02_e2e.txt).
-        if (tunables().zero_copy) {   // (a copy of the knobs as they are now)
+        const Tunables tun = tunables();    // ONE copy of the knobs for this submit
+        if (tun.zero_copy) {
             const uint8_t *zin = pinned_device_ptr(host_in);
             uint8_t *zout = pinned_device_ptr(host_out);
             const bool dense = in_stride == band_in && out_stride == band_out;
@@ -713,7 +714,7 @@ static int submit_common(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_o
                 s.out_staged = false; s.user_out = host_out; s.out_bytes = out_bytes; s.out_band = band_out; s.out_stride = out_stride;
                 s.out_n = n_images;
                 // consecutive zero-copy launches alternate over the first zn streams of the context
-                const int zn = std::max(1, std::min(tunables().zero_copy_streams, (int)c->slots.size()));
+                const int zn = std::max(1, std::min(tun.zero_copy_streams, (int)c->slots.size()));
                 const hipStream_t zs = c->slots[(c->zero_copy_launches % (uint64_t)zn)].stream;
                 // one dispatch packet, nothing else: the kernel's own stop event doubles as the completion event (every
                 // extra hipEventRecord is a barrier packet between two kernels)
@@ -721,8 +722,8 @@ static int submit_common(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_o
                 d.in = zin; d.out = zout; d.width = c->W; d.band_rows = band_rows; d.channels = c->C;
                 d.radius = c->R; d.n_images = n_images; d.y0 = y0; d.y1 = y1; d.variant = MI_BLUR_VARIANT_AUTO;
                 d.in_stride = (long long)in_stride; d.out_stride = (long long)out_stride;
-                if (tunables().zero_copy_server) {
-                    rc = zc_server_submit(c, s, d, tunables());
+                if (tun.zero_copy_server) {
+                    rc = zc_server_submit(c, s, d, tun);
                     if (rc == MI_BLUR_OK) {
                         s.zero_copy = true; s.busy = true;
                         c->tm.bytes_h2d += in_bytes; c->tm.bytes_d2h += out_bytes;
@@ -735,11 +736,11 @@ static int submit_common(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_o
                     if (rc != MI_BLUR_ERR_UNSUPPORTED) return rc;
                     s.zc_server = false;
                 }
-                const bool with_events = tunables().zero_copy_events != 0;
+                const bool with_events = tun.zero_copy_events != 0;
                 d.stream = zs;
                 if (with_events) { d.start = s.ks; d.stop = s.ke; }
                 s.zc_plain = !with_events; s.zc_stream = zs;
-                d.max_blocks = tunables().zero_copy_blocks;
+                d.max_blocks = tun.zero_copy_blocks;
                 // once per sync window, in front of its first launch (and again every ~10 s of a window that never syncs,
                 // so the float milliseconds since the reference keep their resolution)
                 if (with_events && (!c->zc_ref_valid || c->zc_covered_ms > 10e3)) {
