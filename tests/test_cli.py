@@ -432,7 +432,7 @@ def test_bench_a2_two_rank_rehearsal(pkg):
     d = _bench_line(r)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["rows_per_gpu"] == 4096 and d["config"]["halo_bytes_per_neighbour"] == 8192 * 3 and "rehearsal" in d["config"]
-    assert d["config"]["steps_per_form"] == 10 and d["config"]["quoted_form"] in ("plain", "overlapped") and d["config"]["rccl_ranks"] == 0
+    assert d["config"]["steps_per_form"] == 10 and d["config"]["quoted_form"] in ("plain", "overlapped", "pull") and d["config"]["rccl_ranks"] == 0
     assert abs(d["ms_per_step"] * 1e3 - min(d["config"]["step_forms_us"].values())) < 0.06      # value quotes the faster form (ms rounded to 1e-4)
     assert d["parity"]["status"] == "ok" and d["parity"]["a2_8192_rowsplit"]["band_fnv"]["plain"] == "0d04249de0140100"
     dec = d["config"]["step_decomposition"]
