@@ -85,7 +85,8 @@ __device__ __forceinline__ uint32_t mad6(uint32_t c, uint32_t t) { return as_u32
 
 // x-clamp selectors.  Left: the dword holding row-stream bytes [-4q, -4q+3] (q = 1, 2)
 // when the chunk starts the row: byte at position p < 0 is a copy of byte (p mod C)
-// (pixel x<0 clamps to x=0, same channel).  All indices address bytes of chunk dword 0.
+// (pixel x<0 clamps to x=0, same channel).  Indices address the chunk's first EIGHT bytes (v_perm_b32 over chunk dwords
+// 1 and 0), so any C <= 8 works.
 constexpr uint32_t sel_left(int C, int q)
 {
     uint32_t s = 0;
@@ -97,14 +98,14 @@ constexpr uint32_t sel_left(int C, int q)
     return s;
 }
 // Right: the dword holding bytes [pitch+4q, pitch+4q+3] (q = 0, 1) when the chunk ends
-// the row: byte pitch+k is a copy of byte pitch-C+(k mod C).  Indices address bytes of
-// chunk dword 3 (row bytes pitch-4 .. pitch-1).
+// the row: byte pitch+k is a copy of byte pitch-C+(k mod C).  Indices address the chunk's LAST eight bytes (v_perm_b32
+// over chunk dwords 3 and 2: selector 0-3 = row bytes pitch-8 .. pitch-5, 4-7 = pitch-4 .. pitch-1), any C <= 8.
 constexpr uint32_t sel_right(int C, int q)
 {
     uint32_t s = 0;
     for (int j = 0; j < 4; j++) {
         int k = 4 * q + j;
-        int idx = 4 - C + (k % C);
+        int idx = 8 - C + (k % C);
         s |= (uint32_t)idx << (8 * j);
     }
     return s;
@@ -220,10 +221,10 @@ template <int C, int R, int X>
 __device__ __forceinline__ void hrow_window(uint32_t (&w)[8], bool any_edge, bool at_start, bool at_end, uint32_t (&h)[8])
 {
     if (any_edge) {   // wave-uniform: some lane's chunk starts or ends the image row
-        w[1] = at_start ? __builtin_amdgcn_perm(0u, w[2], sel_left(C, 1)) : w[1];
-        w[0] = at_start ? __builtin_amdgcn_perm(0u, w[2], sel_left(C, 2)) : w[0];
-        w[6] = at_end ? __builtin_amdgcn_perm(0u, w[5], sel_right(C, 0)) : w[6];
-        w[7] = at_end ? __builtin_amdgcn_perm(0u, w[5], sel_right(C, 1)) : w[7];
+        w[1] = at_start ? __builtin_amdgcn_perm(w[3], w[2], sel_left(C, 1)) : w[1];
+        w[0] = at_start ? __builtin_amdgcn_perm(w[3], w[2], sel_left(C, 2)) : w[0];
+        w[6] = at_end ? __builtin_amdgcn_perm(w[5], w[4], sel_right(C, 0)) : w[6];
+        w[7] = at_end ? __builtin_amdgcn_perm(w[5], w[4], sel_right(C, 1)) : w[7];
     }
     if constexpr (X == 1) {
         h[0] = hsum_raw<C, R, 0, 0>(w); h[1] = hsum_raw<C, R, 0, 1>(w);
@@ -361,9 +362,9 @@ __device__ __forceinline__ void tiled_tile(const TiledParams &p, unsigned L, Hoo
                         reinterpret_cast<Unaligned16 *>(dst - (16 - p.tail))->v = v;
                         const int len = (16 - p.tail) + (cc == cpr2 - 1 ? 0 : 8);
                         uint8_t *pd = dst + p.tail;
-                        const uint32_t fill[6] = {__builtin_amdgcn_perm(0u, v.w, sel_right(C, 0)), __builtin_amdgcn_perm(0u, v.w, sel_right(C, 1)),
-                                                  __builtin_amdgcn_perm(0u, v.w, sel_right(C, 2)), __builtin_amdgcn_perm(0u, v.w, sel_right(C, 3)),
-                                                  __builtin_amdgcn_perm(0u, v.w, sel_right(C, 4)), __builtin_amdgcn_perm(0u, v.w, sel_right(C, 5))};
+                        const uint32_t fill[6] = {__builtin_amdgcn_perm(v.w, v.z, sel_right(C, 0)), __builtin_amdgcn_perm(v.w, v.z, sel_right(C, 1)),
+                                                  __builtin_amdgcn_perm(v.w, v.z, sel_right(C, 2)), __builtin_amdgcn_perm(v.w, v.z, sel_right(C, 3)),
+                                                  __builtin_amdgcn_perm(v.w, v.z, sel_right(C, 4)), __builtin_amdgcn_perm(v.w, v.z, sel_right(C, 5))};
 #pragma unroll
                         for (int q = 0; q < 6; q++) {
                             if (4 * q + 4 <= len) reinterpret_cast<Unaligned4 *>(pd + 4 * q)->v = fill[q];
@@ -1191,10 +1192,33 @@ static int launch_tiled_cr(const LaunchDesc &d, const TiledParams &p, dim3 grid,
                : do_launch(blur_tiled_kernel<C, R, 8, false>, grid, block, lds, d, p);
 }
 
+// 5 to 8 channels, 3x3 only (the +-C byte taps still fall inside the 8 + 16 + 8-byte window; 5x5 would need +-2C): the
+// LDS-DMA tiled kernel in its aligned and ragged forms, nothing else — the reference kernel is generic in `channels`
+// (gaussian_kernel.cl:44), so frames with more than four planes should not drop to one byte per thread.
+template <int C>
+static int launch_tiled_wide(const LaunchDesc &d, const TiledParams &p, dim3 grid, dim3 block, size_t lds, int rpg, bool ragged)
+{
+    if (ragged)
+        return rpg == 4 ? do_launch(blur_tiled_kernel<C, 1, 4, true, false, true>, grid, block, lds, d, p)
+                        : do_launch(blur_tiled_kernel<C, 1, 8, true, false, true>, grid, block, lds, d, p);
+    return rpg == 4 ? do_launch(blur_tiled_kernel<C, 1, 4, true>, grid, block, lds, d, p)
+                    : do_launch(blur_tiled_kernel<C, 1, 8, true>, grid, block, lds, d, p);
+}
+
+static bool wide_channels(int channels, int radius) { return channels >= 5 && channels <= 8 && radius == 1; }
+
 template <int R>
 static int launch_tiled_r(const LaunchDesc &d, const TiledParams &p, dim3 grid, dim3 block, size_t lds,
                           int rpg, bool dma, bool ragged, bool row_shuffle, int experiment)
 {
+    if constexpr (R == 1) {
+        switch (d.channels) {
+        case 5: return launch_tiled_wide<5>(d, p, grid, block, lds, rpg, ragged);
+        case 6: return launch_tiled_wide<6>(d, p, grid, block, lds, rpg, ragged);
+        case 7: return launch_tiled_wide<7>(d, p, grid, block, lds, rpg, ragged);
+        case 8: return launch_tiled_wide<8>(d, p, grid, block, lds, rpg, ragged);
+        }
+    }
     switch (d.channels) {
     case 1: return launch_tiled_cr<1, R>(d, p, grid, block, lds, rpg, dma, ragged, row_shuffle, experiment);
     case 2: return launch_tiled_cr<2, R>(d, p, grid, block, lds, rpg, dma, ragged, row_shuffle, experiment);
@@ -1240,7 +1264,7 @@ static int tiled_geometry(const LaunchDesc &d, const Tunables &tun, bool ragged,
         const long long waves8 = (long long)d.n_images * rows * cpr / (8 * 64);
         rpg = waves8 < 16384 ? 4 : 8;
     }
-    if ((ragged || fused) && rpg == 16) rpg = 8;
+    if ((ragged || fused || d.channels > 4) && rpg == 16) rpg = 8;
 
     p = TiledParams{};
     p.in = d.in; p.out = d.out;
@@ -1289,7 +1313,7 @@ static int tiled_geometry(const LaunchDesc &d, const Tunables &tun, bool ragged,
 static int launch_tiled(const LaunchDesc &d, const Tunables &tun, bool ragged = false, const FusedDesc *fused = nullptr)
 {
     if (!(fused && fused->geometry_only))
-        g_last_kernel = fused ? "blur_fused_kernel" : (d.max_blocks > 0 && !ragged ? "blur_tiled_loop_kernel" : "blur_tiled_kernel");
+        g_last_kernel = fused ? "blur_fused_kernel" : (d.max_blocks > 0 && !ragged && d.channels <= 4 ? "blur_tiled_loop_kernel" : "blur_tiled_kernel");
     const int R = d.radius;
     TiledParams p{};
     unsigned threads = 0;
@@ -1527,7 +1551,10 @@ int launch(const LaunchDesc &d)
     if ((long long)d.width * d.channels * d.band_rows > INT_MAX) return MI_BLUR_ERR_INVALID;  // per-image 32-bit
     if (d.n_images == 0) return MI_BLUR_OK;
     const Tunables tun = tunables();                  // one coherent set of knobs for this launch
-    const bool can_tile = tiled_eligible(d.in, d.out, d.width, d.channels);
+    const bool wide = wide_channels(d.channels, d.radius);
+    const long long row_bytes = (long long)d.width * d.channels;
+    const bool can_tile = wide ? (row_bytes % 16 == 0 && (uintptr_t)d.in % 16 == 0 && (uintptr_t)d.out % 16 == 0)
+                               : tiled_eligible(d.in, d.out, d.width, d.channels);
     const long long dense_in = (long long)d.band_rows * d.width * d.channels, dense_out = (long long)(d.y1 - d.y0) * d.width * d.channels;
     if ((d.in_stride && d.in_stride != dense_in) || (d.out_stride && d.out_stride != dense_out)) {
         // spaced-out bands (a caller's buffer used in place): tiled kernel only
@@ -1537,10 +1564,11 @@ int launch(const LaunchDesc &d)
         if (d.variant != MI_BLUR_VARIANT_AUTO && d.variant != MI_BLUR_VARIANT_TILED) return MI_BLUR_ERR_UNSUPPORTED;
         return launch_tiled(d, tun);
     }
-    const bool can_rag = ragged_eligible(d.width, d.channels) && tun.ragged;
+    const bool can_rag = (wide ? row_bytes >= 16 : ragged_eligible(d.width, d.channels)) && tun.ragged;
     switch (d.variant) {
     case MI_BLUR_VARIANT_AUTO:
         if (!can_tile) return can_rag ? launch_tiled(d, tun, true) : launch_generic(d);
+        if (wide) return launch_tiled(d, tun);            // the streaming and direct variants exist for 1-4 channels only
         if (tun.prefer_stream) return launch_stream(d, tun);
         // Direct (LDS-free) or tiled?  Measured on MI355X (profiles/r02_direct_kernel.txt): the direct kernel wins every
         // 5x5 launch (5-22 %) and the 3x3 launches that do not fill the chip for long (a batch of 35 256x256 images: 5.4
@@ -1555,8 +1583,8 @@ int launch(const LaunchDesc &d)
         return launch_tiled(d, tun);
     case MI_BLUR_VARIANT_GENERIC: return launch_generic(d);
     case MI_BLUR_VARIANT_TILED: return can_tile ? launch_tiled(d, tun) : can_rag ? launch_tiled(d, tun, true) : MI_BLUR_ERR_INVALID;
-    case MI_BLUR_VARIANT_STREAM: return can_tile ? launch_stream(d, tun) : MI_BLUR_ERR_INVALID;
-    case MI_BLUR_VARIANT_DIRECT: return (can_tile && direct_fits(d)) ? launch_direct(d, tun) : MI_BLUR_ERR_INVALID;
+    case MI_BLUR_VARIANT_STREAM: return (can_tile && !wide) ? launch_stream(d, tun) : MI_BLUR_ERR_INVALID;
+    case MI_BLUR_VARIANT_DIRECT: return (can_tile && !wide && direct_fits(d)) ? launch_direct(d, tun) : MI_BLUR_ERR_INVALID;
     }
     return MI_BLUR_ERR_INVALID;
 }

@@ -52,9 +52,11 @@ typedef enum mi_blur_status {
 /* Kernel variant selector for mi_blur_enqueue_ex (tests force each path). */
 typedef enum mi_blur_variant {
     MI_BLUR_VARIANT_AUTO = 0,        /* pitch%16==0 && channels<=4 && aligned pointers: the direct kernel (5x5; small 3x3 launches) or
-                                        the LDS-tiled one (big 3x3 launches); other rows of >= 16 B: ragged tiled; else generic */
+                                        the LDS-tiled one (big 3x3 launches); other rows of >= 16 B: ragged tiled; 5-8 channels: the tiled
+                                        kernel for the 3x3; else generic */
     MI_BLUR_VARIANT_GENERIC = 1,     /* one output byte per thread, any shape */
-    MI_BLUR_VARIANT_TILED = 2,       /* LDS halo tile + 16-B vector loads (ragged form for odd pitches; _INVALID if C > 4 or rows < 16 B) */
+    MI_BLUR_VARIANT_TILED = 2,       /* LDS halo tile + 16-B vector loads (ragged form for odd pitches; _INVALID if rows < 16 B, C > 8, or
+                                        C > 4 with the 5x5) */
     MI_BLUR_VARIANT_STREAM = 3       /* barrier-free: every wave streams its band through a wave-private LDS row ring
                                         (LDS-DMA, counted vmcnt), sliding window of row sums in registers (same eligibility) */,
     MI_BLUR_VARIANT_DIRECT = 4      /* no LDS: rows straight into registers, x-neighbours by DPP wave shifts (same eligibility) */

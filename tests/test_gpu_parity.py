@@ -253,10 +253,14 @@ def test_auto_dispatch_and_ineligible_tiled(pkg, L, O, torch_cuda):
     assert np.array_equal(gpu_blur(pkg, L, torch_cuda, host, 1, pkg.VARIANT_AUTO), want_batch(O, host, 1))
     d = torch_cuda.zeros(2 * 33 * 17 * 3, dtype=torch_cuda.uint8, device="cuda")
     o = torch_cuda.zeros_like(d)
-    # pitch 51 takes the ragged form of the tiled kernel; rows shorter than one chunk (pitch 15) or C = 5 cannot
+    # pitch 51 takes the ragged form of the tiled kernel; rows shorter than one chunk (pitch 15) cannot; 5 to 8 channels can
+    # for the 3x3 (the +-C taps stay inside the staged window) but not for the 5x5, and 9 channels never
     assert L.mi_blur_enqueue_ex(d.data_ptr(), o.data_ptr(), 17, 33, 3, 1, 2, 0, 33, pkg.VARIANT_TILED, None) == pkg.OK
     assert L.mi_blur_enqueue_ex(d.data_ptr(), o.data_ptr(), 5, 33, 3, 1, 2, 0, 33, pkg.VARIANT_TILED, None) == pkg.ERR_INVALID
-    assert L.mi_blur_enqueue_ex(d.data_ptr(), o.data_ptr(), 17, 19, 5, 1, 2, 0, 19, pkg.VARIANT_TILED, None) == pkg.ERR_INVALID
+    assert L.mi_blur_enqueue_ex(d.data_ptr(), o.data_ptr(), 17, 19, 5, 1, 2, 0, 19, pkg.VARIANT_TILED, None) == pkg.OK
+    assert L.mi_blur_enqueue_ex(d.data_ptr(), o.data_ptr(), 17, 19, 5, 2, 2, 0, 19, pkg.VARIANT_TILED, None) == pkg.ERR_INVALID
+    assert L.mi_blur_enqueue_ex(d.data_ptr(), o.data_ptr(), 17, 11, 9, 1, 2, 0, 11, pkg.VARIANT_TILED, None) == pkg.ERR_INVALID
+    assert L.mi_blur_enqueue_ex(d.data_ptr(), o.data_ptr(), 16, 19, 5, 1, 2, 0, 19, pkg.VARIANT_DIRECT, None) == pkg.ERR_INVALID
     assert L.mi_blur_enqueue_ex(d.data_ptr(), o.data_ptr(), 17, 33, 3, 1, 2, 0, 33, pkg.VARIANT_STREAM, None) == pkg.ERR_INVALID
     assert L.mi_blur_enqueue_ex(d.data_ptr(), d.data_ptr(), 17, 33, 3, 1, 2, 0, 33, 0, None) == pkg.ERR_INVALID
     assert L.mi_blur_enqueue_ex(d.data_ptr(), o.data_ptr(), 17, 33, 3, 3, 2, 0, 33, 0, None) == pkg.ERR_INVALID
@@ -270,6 +274,44 @@ def test_auto_dispatch_and_ineligible_tiled(pkg, L, O, torch_cuda):
     pkg.check(L.mi_blur_enqueue(buf.data_ptr() + 3, out.data_ptr() + 5, 16, 16, 3, 1, 1, None))
     torch_cuda.cuda.synchronize()
     assert np.array_equal(out[5:5 + host.size].cpu().numpy().reshape(host.shape), want_batch(O, host, 1))
+
+
+WIDE_SHAPES = [(33, 16, 5), (64, 80, 6), (40, 48, 7), (96, 64, 8), (17, 33, 5), (50, 37, 6), (9, 129, 7), (31, 29, 8), (2, 4, 8),
+               (240, 320, 6), (3, 1000, 5)]
+
+
+@pytest.mark.parametrize("h,w,c", WIDE_SHAPES)
+def test_five_to_eight_channel_frames_take_the_tiled_kernel(pkg, L, O, torch_cuda, h, w, c):
+    """The reference kernel is generic in `channels` (gaussian_kernel.cl:44).  For the 3x3, frames of 5 to 8 channels run
+    the LDS-DMA tiled kernel (aligned and ragged rows) — the +-C byte taps still fall inside the 8 + 16 + 8-byte window and
+    the x-clamp selectors reach over two dwords; the 5x5 of such frames (+-2C) stays on the generic kernel.  Bit-exact vs
+    the oracle on adversarial images, batches, bands, odd pointer offsets, every rows-per-thread setting."""
+    n = 3
+    torch = torch_cuda
+    try:
+        for host in adversarial(O, h, w, c, n, h * 7 + w + c):
+            want = want_batch(O, host, 1)
+            for opts in ({"rows_per_thread": 0}, {"rows_per_thread": 4}, {"rows_per_thread": 8, "xcd_remap": 0}, {"rows_per_thread": 16}):
+                for variant in (pkg.VARIANT_AUTO, pkg.VARIANT_TILED):
+                    got = gpu_blur(pkg, L, torch, host, 1, variant, opts=opts)
+                    assert np.array_equal(got, want), f"{(got != want).sum()} bytes differ, opts={opts}"
+                    assert L.mi_blur_last_kernel() == b"blur_tiled_kernel"
+        host = O.lcg_stream(n, h, w, c)
+        assert np.array_equal(gpu_blur(pkg, L, torch, host, 2, pkg.VARIANT_AUTO), want_batch(O, host, 2))
+        assert L.mi_blur_last_kernel() == b"blur_generic_kernel"
+        want = want_batch(O, host, 1)
+        if h >= 3:
+            assert np.array_equal(gpu_blur(pkg, L, torch, host, 1, pkg.VARIANT_AUTO, y0=1, y1=h - 1), want[:, 1:h - 1])
+        buf = torch.full((host.size + 64,), 0xA5, dtype=torch.uint8, device="cuda")
+        out = torch.full((host.size + 64,), 0x5A, dtype=torch.uint8, device="cuda")
+        buf[1:1 + host.size] = torch.from_numpy(host.reshape(-1)).cuda()
+        pkg.check(L.mi_blur_enqueue(buf.data_ptr() + 1, out.data_ptr() + 7, w, h, c, 1, n, None))
+        torch.cuda.synchronize()
+        res = out.cpu().numpy()
+        assert np.array_equal(res[7:7 + host.size].reshape(host.shape), want)
+        assert (res[:7] == 0x5A).all() and (res[7 + host.size:] == 0x5A).all()
+    finally:
+        reset_opts(L)
 
 
 RAGGED_SHAPES = [(33, 17, 3), (5, 16, 1), (1, 17, 1), (2, 6, 3), (31, 29, 4), (40, 250, 3), (64, 1366, 3), (19, 1000, 3),
