@@ -170,6 +170,7 @@ def lib() -> C.CDLL:
         "mi_blur_comm_init_rank": (i, [C.POINTER(vp), i, i, vp]),
         "mi_blur_comm_init_all": (i, [C.POINTER(vp), i, C.POINTER(i)]),
         "mi_blur_comm_init_p2p": (i, [C.POINTER(vp), i, C.POINTER(i)]),
+        "mi_blur_comm_init_pull": (i, [C.POINTER(vp), i, C.POINTER(i)]),
         "mi_blur_comm_destroy": (None, [vp]),
         "mi_blur_comm_info": (i, [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]),
         "mi_blur_halo_exchange": (i, [vp, u8p, i, i, i, i, vp]),

@@ -249,13 +249,14 @@ static int run_resident(const Options &opt)
     const int W = opt.size_given ? opt.syn_w : 8192, H = opt.size_given ? opt.syn_h : 8192, C = opt.syn_c;
     const size_t pitch = (size_t)W * C;
     if (!gpus_available(G)) { printf("Error: %d GPU(s) asked, %d visible\n", G, mi_blur_device_count()); return -1; }
-    const bool p2p = opt.transport == "p2p" || virtual_gpus();      // RCCL refuses two ranks on one device
+    const bool pull = opt.transport == "pull";
+    const bool p2p = opt.transport == "p2p" || (virtual_gpus() && !pull);      // RCCL refuses two ranks on one device
     if (H / G < radius) { printf("Error: shards of %d rows are thinner than the halo\n", H / G); return -1; }
     printf("========== SPLIT-IMAGE (RESIDENT, MULTI-GPU) ==========\n");
     printf("Image: %dx%d, %d channels (%.2f MB), %dx%d blur, %d GPU(s), %d iterations\n", W, H, C, pitch * H / 1e6, opt.ksize,
            opt.ksize, G, opt.iters);
     printf("Halo: %d row(s) = %zu bytes per neighbour per direction, %s\n\n", radius, radius * pitch,
-           p2p ? "hipMemcpyPeerAsync pushes" : "RCCL send/recv");
+           pull ? "pulled by one kernel per GPU (peer reads)" : p2p ? "hipMemcpyPeerAsync pushes" : "RCCL send/recv");
 
     std::vector<uint8_t> image(pitch * H);
     mi_blur_fill_synthetic(image.data(), W, H, C, 0, 1, 0);
@@ -279,7 +280,8 @@ static int run_resident(const Options &opt)
         printf("GPU %d: rows %d-%d (+%d/+%d halo)\n", g, band[g].row_begin, band[g].row_end - 1, band[g].halo_top, band[g].halo_bottom);
     }
     std::vector<mi_blur_comm *> comm(G, nullptr);
-    mi_check(p2p ? mi_blur_comm_init_p2p(comm.data(), G, devs.data()) : mi_blur_comm_init_all(comm.data(), G, devs.data()),
+    mi_check(pull ? mi_blur_comm_init_pull(comm.data(), G, devs.data())
+                  : p2p ? mi_blur_comm_init_p2p(comm.data(), G, devs.data()) : mi_blur_comm_init_all(comm.data(), G, devs.data()),
              "communicator init failed");
 
     // --iterate: k successive blurs of the resident image (output shard -> next input shard), the case where the

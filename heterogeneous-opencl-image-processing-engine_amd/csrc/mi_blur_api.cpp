@@ -1323,6 +1323,7 @@ struct mi_blur_comm {
     ncclComm_t comm = nullptr;
     int n_ranks = 1, rank = 0, device = -1;
     bool p2p = false;                            // single-process copy transport instead of RCCL
+    bool pull = false;                           // ... whose copies are PULLS: one small kernel per rank reads the neighbours' rows
     hipEvent_t ev_prev = nullptr, ev_push = nullptr;
 };
 
@@ -1424,12 +1425,22 @@ extern "C" int mi_blur_comm_init_p2p(mi_blur_comm **comms, int n_devices, const 
     return MI_BLUR_OK;
 }
 
+// The same single-process set with the halo rows PULLED: every rank runs one small kernel (mi_blur_halo_pull's) that reads its
+// neighbours' edge rows through peer access, instead of pushing its own with two hipMemcpyPeerAsync.
+extern "C" int mi_blur_comm_init_pull(mi_blur_comm **comms, int n_devices, const int *devices)
+{
+    const int rc = mi_blur_comm_init_p2p(comms, n_devices, devices);
+    if (rc) return rc;
+    for (int i = 0; i < n_devices; i++) comms[i]->pull = true;
+    return MI_BLUR_OK;
+}
+
 // What a communicator IS, as the transport itself reports it: a bench line that says "RCCL carried the halos over N
 // ranks" quotes ncclCommCount / ncclCommUserRank, not the number it asked for.
 extern "C" int mi_blur_comm_info(mi_blur_comm *c, int *n_ranks, int *rank, int *transport)
 {
     if (!c) return MI_BLUR_ERR_INVALID;
-    int n = c->n_ranks, r = c->rank, t = c->p2p ? 2 : (c->comm ? 1 : 0);
+    int n = c->n_ranks, r = c->rank, t = c->pull ? 3 : c->p2p ? 2 : (c->comm ? 1 : 0);
     if (c->comm) {
         Rccl &rc = rccl();
         if (!rc.ok || !rc.CommCount || !rc.CommUserRank) return MI_BLUR_ERR_UNSUPPORTED;
@@ -1560,6 +1571,25 @@ extern "C" int mi_blur_halo_exchange_all(mi_blur_comm **comms, int n, uint8_t **
         }
         for (int i = 0; i < n; i++) {
             HIP_TRY(hipSetDevice(comms[i]->device));
+            if (comms[0]->pull) {
+                // PULL: rank i reads the last owned rows of rank i-1 and the first owned rows of rank i+1 into its own halo rows
+                // with one kernel on its own stream, once both neighbours have finished what they queued before this call
+                // (their owned rows are final).  ev_push(i) = "rank i has read its neighbours' rows": they wait for it below
+                // before anything they queue later may overwrite those rows.
+                const uint8_t *top_src = nullptr, *bottom_src = nullptr;
+                if (i > 0) {
+                    HIP_TRY(hipStreamWaitEvent(st(i), comms[i - 1]->ev_prev, 0));
+                    top_src = d_bands[i - 1] + (size_t)(top(i - 1) + owned_rows[i - 1] - radius) * pitch;
+                }
+                if (i < n - 1) {
+                    HIP_TRY(hipStreamWaitEvent(st(i), comms[i + 1]->ev_prev, 0));
+                    bottom_src = d_bands[i + 1] + (size_t)top(i + 1) * pitch;
+                }
+                const int rc = launch_halo_pull(top_src, d_bands[i], bottom_src, d_bands[i] + (size_t)(top(i) + owned_rows[i]) * pitch, nbytes, st(i));
+                if (rc) return rc;
+                HIP_TRY(hipEventRecord(comms[i]->ev_push, st(i)));
+                continue;
+            }
             if (i > 0) {          // first owned rows -> bottom halo of rank i-1
                 HIP_TRY(hipStreamWaitEvent(st(i), comms[i - 1]->ev_prev, 0));
                 uint8_t *dst = d_bands[i - 1] + (size_t)(top(i - 1) + owned_rows[i - 1]) * pitch;

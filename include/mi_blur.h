@@ -384,10 +384,13 @@ int mi_blur_comm_init_all(mi_blur_comm **comms, int n_devices, const int *device
 /* Single-process set that moves halo rows with hipMemcpyPeerAsync instead of RCCL (fallback transport; also the
  * only one that accepts several ranks on one device).  Use with mi_blur_halo_exchange_all. */
 int mi_blur_comm_init_p2p(mi_blur_comm **comms, int n_devices, const int *devices);
+/* The same single-process set with the halo rows PULLED by one small kernel per rank (mi_blur_halo_pull's) instead of pushed
+ * with two peer copies; ordering by the same events.  Use with mi_blur_halo_exchange_all. */
+int mi_blur_comm_init_pull(mi_blur_comm **comms, int n_devices, const int *devices);
 void mi_blur_comm_destroy(mi_blur_comm *comm);
 /* What the communicator is, as its transport reports it: *n_ranks / *rank from ncclCommCount / ncclCommUserRank for an
  * RCCL communicator (the numbers a report should quote for "RCCL carried the halos over N ranks"), the construction
- * arguments otherwise; *transport 0 = none (a single rank: both image edges clamp), 1 = RCCL, 2 = peer copies.
+ * arguments otherwise; *transport 0 = none (a single rank: both image edges clamp), 1 = RCCL, 2 = peer copies, 3 = pulled by a kernel.
  * Any out pointer may be NULL. */
 int mi_blur_comm_info(mi_blur_comm *comm, int *n_ranks, int *rank, int *transport);
 

@@ -525,6 +525,16 @@ def test_resident_row_shards_on_virtual_gpus(apps, O, tmp_path):
             for _ in range(passes):
                 want = O.blur(want, radius)
             assert np.array_equal(read_ppm(tmp_path / fname), want), (ksize, extra)
+        # the third transport: halo rows PULLED by one small kernel per shard that reads its neighbours' rows (ordering by the
+        # same events as the pushes) — single blur, iterated, and iterated with the exchange hidden behind the interior rows
+        for extra, fname, passes in (([], "pl_one.ppm", 1), (["--iterate"], "pl_it.ppm", 4), (["--iterate", "--overlap"], "pl_ov.ppm", 4)):
+            r = subprocess.run([spl, "--resident", "--transport", "pull", "--gpus", "4", "--size", "320x240", "--ksize", ksize, "--iters", "4",
+                                "--save", fname] + extra, cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
+            assert r.returncode == 0 and "EQUALS the single-device blur" in r.stdout and "pulled by one kernel per GPU" in r.stdout, r.stdout + r.stderr
+            want = src
+            for _ in range(passes):
+                want = O.blur(want, radius)
+            assert np.array_equal(read_ppm(tmp_path / fname), want), (ksize, extra, "pull")
 
 
 @pytest.mark.gpu
