@@ -805,6 +805,7 @@ def main() -> None:
             alt = pkg.Context(local_rank, w, h, c, radius, max_batch=1, n_slots=4, n_threads=host_threads)
         ctx = pkg.Context(local_rank, w, h, c, radius, max_batch=1, n_slots=args.streams, n_threads=host_threads)   # resident runs use no staging
         ctx.resident_alloc(pool)
+        pool_placement = ctx.resident_placement()                  # the library tried a few placements of the pool and kept the fastest
         first, _ = shard_range(per_gpu * world, rank, world)       # image-level sharding: rank g owns [first, first + per_gpu)
         # test hook (tests/test_cli.py): the last rank loads the WRONG shard, to show that the parity check fails the job
         wrong = 1 if (os.environ.get("MI_BLUR_BENCH_FAULT") == "wrong_shard" and rank == world - 1) else 0
@@ -869,6 +870,10 @@ def main() -> None:
             config["batches_counted_in_last_pass"] = ctx.resident_batches_done()
         if per_rank:
             config["per_rank"] = per_rank
+        if pool_placement["candidates_us"]:
+            config["pool_placement"] = dict(pool_placement, what="mi_blur_resident_alloc timed this many candidate placements of the pool "
+                                                                 "(one launch over the whole pool each) and kept the fastest: where a pool "
+                                                                 "lands in HBM moves the big launches between two levels ~6 % apart")
 
         # ---- parity (after the clock has stopped): EVERY output image of this rank's shard is downloaded, hashed and compared
         # with the unmodified reference kernel's hash of the same image of the stream (tests/golden/stream50k_image_fnv.npy).

@@ -150,6 +150,7 @@ def lib() -> C.CDLL:
         "mi_blur_resident_peek": (C.c_int, [vp, C.c_int, u8p, C.c_int]),
         "mi_blur_zero_copy_launches": (C.c_uint64, [vp]),
         "mi_blur_resident_alloc": (i, [vp, i]),
+        "mi_blur_resident_placement": (i, [vp, C.POINTER(C.c_float), i, C.POINTER(i)]),
         "mi_blur_resident_fill_synthetic": (i, [vp, i]),
         "mi_blur_resident_upload": (i, [vp, i, u8p, i]),
         "mi_blur_resident_download": (i, [vp, i, u8p, i]),
@@ -282,6 +283,13 @@ class Context:
 
     def resident_alloc(self, pool_images: int) -> None:
         check(lib().mi_blur_resident_alloc(self.h, pool_images), "mi_blur_resident_alloc")
+
+    def resident_placement(self) -> dict:
+        """What resident_alloc measured when it chose the pool: per-launch us of each candidate placement, and the one kept."""
+        ms = (C.c_float * 8)()
+        kept = C.c_int()
+        n = lib().mi_blur_resident_placement(self.h, ms, 8, C.byref(kept))
+        return {"candidates_us": [round(ms[k] * 1e3, 2) for k in range(max(n, 0))], "kept": kept.value}
 
     def resident_fill_synthetic(self, first_index: int = 0) -> None:
         check(lib().mi_blur_resident_fill_synthetic(self.h, first_index), "mi_blur_resident_fill_synthetic")

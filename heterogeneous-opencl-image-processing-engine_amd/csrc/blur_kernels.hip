@@ -110,6 +110,21 @@ constexpr uint32_t sel_right(int C, int q)
     }
     return s;
 }
+// The clamp dwords themselves.  For C <= 4 every selected byte lies in ONE dword (the chunk's first / last), and the perm is
+// written with that dword alone: with two live operands hipcc schedules the whole tile loop differently (39 instead of 54
+// VGPRs, loads no longer hoisted) and the 3x3 stream loses 20 % — so the two-dword form is kept to C > 4, where it is needed.
+template <int C>
+__device__ __forceinline__ uint32_t clamp_left(uint32_t d0, uint32_t d1, int q)
+{
+    if constexpr (C <= 4) { (void)d1; return q == 1 ? __builtin_amdgcn_perm(0u, d0, sel_left(C, 1)) : __builtin_amdgcn_perm(0u, d0, sel_left(C, 2)); }
+    else return q == 1 ? __builtin_amdgcn_perm(d1, d0, sel_left(C, 1)) : __builtin_amdgcn_perm(d1, d0, sel_left(C, 2));
+}
+template <int C, int Q>
+__device__ __forceinline__ uint32_t clamp_right(uint32_t d2, uint32_t d3)
+{
+    if constexpr (C <= 4) { (void)d2; return __builtin_amdgcn_perm(0u, d3, sel_right(C, Q) - 0x04040404u); }   // indices 4..7 -> 0..3 of d3 alone
+    else return __builtin_amdgcn_perm(d3, d2, sel_right(C, Q));
+}
 
 // Ew[j] / Ow[j] = even / odd bytes of window dword j, the window being row-stream bytes
 // [-8, 24) around this thread's chunk (chunk = dwords 2..5).  tap<K, PI, I> = the two
@@ -221,10 +236,10 @@ template <int C, int R, int X>
 __device__ __forceinline__ void hrow_window(uint32_t (&w)[8], bool any_edge, bool at_start, bool at_end, uint32_t (&h)[8])
 {
     if (any_edge) {   // wave-uniform: some lane's chunk starts or ends the image row
-        w[1] = at_start ? __builtin_amdgcn_perm(w[3], w[2], sel_left(C, 1)) : w[1];
-        w[0] = at_start ? __builtin_amdgcn_perm(w[3], w[2], sel_left(C, 2)) : w[0];
-        w[6] = at_end ? __builtin_amdgcn_perm(w[5], w[4], sel_right(C, 0)) : w[6];
-        w[7] = at_end ? __builtin_amdgcn_perm(w[5], w[4], sel_right(C, 1)) : w[7];
+        w[1] = at_start ? clamp_left<C>(w[2], w[3], 1) : w[1];
+        w[0] = at_start ? clamp_left<C>(w[2], w[3], 2) : w[0];
+        w[6] = at_end ? clamp_right<C, 0>(w[4], w[5]) : w[6];
+        w[7] = at_end ? clamp_right<C, 1>(w[4], w[5]) : w[7];
     }
     if constexpr (X == 1) {
         h[0] = hsum_raw<C, R, 0, 0>(w); h[1] = hsum_raw<C, R, 0, 1>(w);
@@ -362,9 +377,8 @@ __device__ __forceinline__ void tiled_tile(const TiledParams &p, unsigned L, Hoo
                         reinterpret_cast<Unaligned16 *>(dst - (16 - p.tail))->v = v;
                         const int len = (16 - p.tail) + (cc == cpr2 - 1 ? 0 : 8);
                         uint8_t *pd = dst + p.tail;
-                        const uint32_t fill[6] = {__builtin_amdgcn_perm(v.w, v.z, sel_right(C, 0)), __builtin_amdgcn_perm(v.w, v.z, sel_right(C, 1)),
-                                                  __builtin_amdgcn_perm(v.w, v.z, sel_right(C, 2)), __builtin_amdgcn_perm(v.w, v.z, sel_right(C, 3)),
-                                                  __builtin_amdgcn_perm(v.w, v.z, sel_right(C, 4)), __builtin_amdgcn_perm(v.w, v.z, sel_right(C, 5))};
+                        const uint32_t fill[6] = {clamp_right<C, 0>(v.z, v.w), clamp_right<C, 1>(v.z, v.w), clamp_right<C, 2>(v.z, v.w),
+                                                  clamp_right<C, 3>(v.z, v.w), clamp_right<C, 4>(v.z, v.w), clamp_right<C, 5>(v.z, v.w)};
 #pragma unroll
                         for (int q = 0; q < 6; q++) {
                             if (4 * q + 4 <= len) reinterpret_cast<Unaligned4 *>(pd + 4 * q)->v = fill[q];
@@ -1092,6 +1106,8 @@ static Tunables &tunables_storage()
         v.zero_copy_streams = 4; v.zero_copy_blocks = 24; v.stream_updown = 1; v.prefer_direct = 1; v.direct_bh = 8; v.fused_window = 8;
         v.zero_copy_server = 1; v.zero_copy_workers = 48; v.zero_copy_idle_us = 300; v.zero_copy_budget = 256; v.zero_copy_tickets = 1;
         v.zero_copy_events = 1;
+        v.resident_place_trials = 4;
+        if (const char *e = getenv("MI_BLUR_PLACE_TRIALS")) { const int r = atoi(e); if (r >= 0 && r <= 8) v.resident_place_trials = r; }
         if (const char *e = getenv("MI_BLUR_STAGE")) v.stage_dma = strcmp(e, "reg") != 0;
         if (const char *e = getenv("MI_BLUR_RPG")) { const int r = atoi(e); v.rpg = (r == 4 || r == 8 || r == 16) ? r : 0; }
         if (const char *e = getenv("MI_BLUR_XCD")) v.xcd_remap = atoi(e) != 0;

@@ -130,6 +130,7 @@ struct Tunables {
     int zero_copy_idle_us; // batch server: leaves after this long without a new batch (default 300)
     int zero_copy_budget;  // batch server: leaves after this many batches, the queued next one carries on (default 256)
     int zero_copy_tickets; // batch server: 1 (default) = tiles by ticket counter, 0 = fixed share per worker (tile g to worker g mod n; A/B only)
+    int resident_place_trials; // mi_blur_resident_alloc: candidate placements of a big pool that are timed before one is kept (default 4; 0/1 = none)
     int zero_copy_spin;    // waiting for a batch of the server: 0 (default) = spin ~20 us, then sleep in 20 us steps; 1 = spin + yield only
     int zero_copy_trace;   // diagnostics: the batch server's workers stamp their phases per batch (mi_blur_debug_zc_trace)
     int zero_copy_events; // zero-copy submits: 1 = the dispatch carries start/stop timestamp events (kernel bucket + completion),

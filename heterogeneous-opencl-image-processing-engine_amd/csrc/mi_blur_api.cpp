@@ -105,6 +105,7 @@ extern "C" int mi_blur_set_option(const char *key, int value)
     else if (!strcmp(key, "zero_copy_trace")) t.zero_copy_trace = value != 0;
     else if (!strcmp(key, "zero_copy_tickets")) t.zero_copy_tickets = value != 0;
     else if (!strcmp(key, "zero_copy_spin")) t.zero_copy_spin = value != 0;
+    else if (!strcmp(key, "resident_place_trials")) { if (value < 0 || value > 8) return MI_BLUR_ERR_INVALID; t.resident_place_trials = value; }
     else if (!strcmp(key, "zero_copy_workers")) { if (value < 1 || value > 2048) return MI_BLUR_ERR_INVALID; t.zero_copy_workers = value; }
     else if (!strcmp(key, "zero_copy_idle_us")) { if (value < 10 || value > 100000) return MI_BLUR_ERR_INVALID; t.zero_copy_idle_us = value; }
     else if (!strcmp(key, "zero_copy_budget")) { if (value < 1 || value > (1 << 20)) return MI_BLUR_ERR_INVALID; t.zero_copy_budget = value; }
@@ -239,6 +240,8 @@ struct mi_blur_ctx {
     unsigned fused_watch_seq = 0;                                // sequence number of the latest watched pass (0 = none)
     bool fused_watched = false;                                  // the latest pass has a watcher
     ZcServer *zc = nullptr;                                      // batch server, made on the first submit that can use it
+    std::vector<float> place_ms;                                 // resident pool: per-launch ms of each candidate placement tried
+    int place_kept = 0;
     // CPU device
     std::vector<CpuJob *> cpu_jobs;
     bool is_cpu() const { return device == MI_BLUR_DEVICE_CPU; }
@@ -927,6 +930,76 @@ extern "C" int mi_blur_wait_oldest(mi_blur_ctx *c)
 // ----------------------------------------------------------------------------------
 // device-resident stream
 // ----------------------------------------------------------------------------------
+// Where a pool lands in HBM moves the big launches between two levels ~6 % apart (1080p 5x5: 138 <-> 148 us; the 3x3
+// stream: 322 <-> 345 us): same request counts on every channel, but 1.5x the read DRAM-credit stalls on the slow
+// placements (profiles/r03_placement_channels.txt).  Nothing in the address says which it will be, and hipMalloc offers no
+// handle on it — but a placement keeps its level for as long as it lives, so the pool is CHOSEN: "resident_place_trials"
+// candidate (in, out) pairs are allocated side by side, each is timed on the launch the pool is for (the context's kernel
+// over the whole pool, timings interleaved and after a clock ramp), the fastest is kept and the others are freed.
+static int place_pool(mi_blur_ctx *c, size_t bytes, int pool_images, int trials)
+{
+    struct Cand { uint8_t *in = nullptr, *out = nullptr; float best_ms = 1e30f; };
+    std::vector<Cand> cand((size_t)trials);
+    auto release = [&](int keep) {
+        for (int i = 0; i < trials; i++) {
+            if (i == keep) continue;
+            if (cand[i].in) (void)hipFree(cand[i].in);
+            if (cand[i].out) (void)hipFree(cand[i].out);
+        }
+    };
+    int n_ok = 0;
+    for (int i = 0; i < trials; i++) {
+        if (hipMalloc((void **)&cand[i].in, bytes) != hipSuccess || hipMalloc((void **)&cand[i].out, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            if (cand[i].in) { (void)hipFree(cand[i].in); cand[i].in = nullptr; }
+            break;                                              // memory is short: choose among what there is
+        }
+        n_ok++;
+    }
+    if (n_ok == 0) return MI_BLUR_ERR_HIP_BASE - (int)hipErrorOutOfMemory;
+    c->place_ms.clear();
+    int keep = 0;
+    if (n_ok > 1) {
+        hipStream_t st = c->slots[0].stream;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+            auto pass = [&](Cand &k) {
+                LaunchDesc d{};
+                d.in = k.in; d.out = k.out; d.width = c->W; d.band_rows = c->H; d.channels = c->C; d.radius = c->R;
+                d.n_images = pool_images; d.y0 = 0; d.y1 = c->H; d.variant = MI_BLUR_VARIANT_AUTO; d.stream = st;
+                return launch(d);
+            };
+            int rc = MI_BLUR_OK;
+            const auto t0 = std::chrono::steady_clock::now();      // ~50 ms of launches first: the clocks ramp (r02_clock_ramp.txt)
+            while (rc == MI_BLUR_OK && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(50)) {
+                for (int r = 0; r < 4 && rc == MI_BLUR_OK; r++) rc = pass(cand[0]);
+                if (hipStreamSynchronize(st) != hipSuccess) rc = MI_BLUR_ERR_STATE;
+            }
+            for (int round = 0; round < 3 && rc == MI_BLUR_OK; round++)
+                for (int i = 0; i < n_ok && rc == MI_BLUR_OK; i++) {
+                    rc = pass(cand[i]);                             // one untimed launch: this candidate's lines and TLB entries
+                    (void)hipEventRecord(e0, st);
+                    for (int r = 0; r < 3 && rc == MI_BLUR_OK; r++) rc = pass(cand[i]);
+                    (void)hipEventRecord(e1, st);
+                    float ms = 0.f;
+                    if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.f)
+                        cand[i].best_ms = std::min(cand[i].best_ms, ms / 3.0f);
+                }
+            (void)hipGetLastError();
+            for (int i = 0; i < n_ok; i++) {
+                c->place_ms.push_back(cand[i].best_ms);
+                if (cand[i].best_ms < cand[keep].best_ms) keep = i;
+            }
+        }
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+    c->pool_in = cand[keep].in; c->pool_out = cand[keep].out;
+    c->place_kept = keep;
+    release(keep);
+    return MI_BLUR_OK;
+}
+
 extern "C" int mi_blur_resident_alloc(mi_blur_ctx *c, int pool_images)
 {
     if (!c || pool_images <= 0) return MI_BLUR_ERR_INVALID;
@@ -936,10 +1009,29 @@ extern "C" int mi_blur_resident_alloc(mi_blur_ctx *c, int pool_images)
     if (c->pool_out) { (void)hipFree(c->pool_out); c->pool_out = nullptr; }
     c->pool_images = 0; c->cursor = 0;
     const size_t bytes = c->image_bytes * (size_t)pool_images;
-    HIP_TRY(hipMalloc((void **)&c->pool_in, bytes));
-    HIP_TRY(hipMalloc((void **)&c->pool_out, bytes));
+    // placement only matters to launches that stream hundreds of MB; candidates are only tried while they are cheap to hold
+    const int trials = tunables().resident_place_trials;
+    if (trials > 1 && bytes >= ((size_t)128 << 20) && bytes <= ((size_t)8 << 30)) {
+        int rc = place_pool(c, bytes, pool_images, std::min(trials, 8));
+        if (rc) return rc;
+    } else {
+        c->place_ms.clear(); c->place_kept = 0;
+        HIP_TRY(hipMalloc((void **)&c->pool_in, bytes));
+        HIP_TRY(hipMalloc((void **)&c->pool_out, bytes));
+    }
     c->pool_images = pool_images;
     return MI_BLUR_OK;
+}
+
+// What mi_blur_resident_alloc measured when it chose the pool: the per-launch time (ms) of each candidate placement, and
+// which one it kept.  n = 0: no trial was run (small pool, "resident_place_trials" <= 1).
+extern "C" int mi_blur_resident_placement(mi_blur_ctx *c, float *ms, int max_n, int *kept)
+{
+    if (!c) return MI_BLUR_ERR_INVALID;
+    const int n = (int)std::min<size_t>(c->place_ms.size(), (size_t)std::max(max_n, 0));
+    for (int i = 0; i < n && ms; i++) ms[i] = c->place_ms[i];
+    if (kept) *kept = c->place_kept;
+    return n;
 }
 
 extern "C" int mi_blur_resident_upload(mi_blur_ctx *c, int pool_index, const uint8_t *host_in, int n_images)

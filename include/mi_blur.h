@@ -99,6 +99,7 @@ const char *mi_blur_last_kernel(void);
  *   "zero_copy_idle_us" 300 (default): a server leaves after this long without a new batch (the next submit starts one)
  *   "zero_copy_budget"  256 (default): ... and after this many batches; the next one, already queued behind it, carries on
  *   "zero_copy_tickets" 1 (default) | 0 = a fixed share of tiles per worker (A/B runs: what a per-batch launch does)
+ *   "resident_place_trials" 4 (default): see mi_blur_resident_alloc
  *   "zero_copy_spin"    0 (default) = a wait for a batch of the server spins ~20 us, then sleeps in 20 us steps (the core is
  *                      free for the threads that build the next batch); 1 = spin + yield only
  *   "zero_copy_trace"   0 (default) | 1 = the server's workers stamp their phases (mi_blur_debug_zc_trace)
@@ -273,7 +274,14 @@ int mi_blur_interleaved_to_planar(const uint8_t *d_interleaved, uint8_t *d_plana
  * Device-resident stream (no reference analogue: the reference re-uploads
  * every image).  The pool holds pool_images images in HBM (in + out).
  * ---------------------------------------------------------------------- */
+/* Pools of 128 MiB .. 8 GiB are PLACED: where a pool lands in HBM moves the big launches between two levels ~6 % apart
+ * (profiles/r03_placement_channels.txt: same requests per channel, 1.5x the read DRAM-credit stalls on the slow placements),
+ * nothing in the address tells which, and a placement keeps its level while it lives — so "resident_place_trials" (default 4;
+ * MI_BLUR_PLACE_TRIALS in the environment; 0/1 = off) candidate (in, out) pairs are allocated side by side, each is timed on
+ * the context's kernel over the whole pool (after a clock ramp, interleaved), the fastest is kept, the others are freed
+ * (~0.1 s, once per pool).  mi_blur_resident_placement reports the candidates' per-launch ms and which one was kept. */
 int mi_blur_resident_alloc(mi_blur_ctx *ctx, int pool_images);
+int mi_blur_resident_placement(mi_blur_ctx *ctx, float *ms, int max_n, int *kept);
 /* Fill pool image i with the synthetic LCG image (seed 0x9E3779B9 ^ (first_index+i)). */
 int mi_blur_resident_fill_synthetic(mi_blur_ctx *ctx, int first_index);
 int mi_blur_resident_upload(mi_blur_ctx *ctx, int pool_index, const uint8_t *host_in, int n_images);

@@ -185,3 +185,31 @@ def test_synthetic_stream_matches_oracle_generator(pkg, L, O):
     L.mi_blur_fill_synthetic(a.ctypes.data, 12, 8, 3, 40, 5, 3)
     assert np.array_equal(a, O.lcg_stream(5, 8, 12, 3, first_index=40))
     assert L.mi_blur_fnv1a64(a.ctypes.data, a.size) == O.fnv1a64(a)
+
+
+def test_hot_kernels_keep_their_register_budget(pkg, tmp_path):
+    """hipcc's schedule of the tile loop is fragile: in round 3 a two-operand v_perm in the x-clamp (needed only for more than
+    four channels) made it allocate 39 VGPRs instead of 54 for the 3x3 kernels — loads no longer hoisted — and the headline
+    stream lost 20 % without a single test failing.  This compiles the kernels to gfx950 assembly (no GPU needed) and pins
+    the VGPR counts of the hot instantiations to the ranges they were tuned in."""
+    import re
+    out = tmp_path / "k.s"
+    r = subprocess.run([pkg.HIPCC, f"--offload-arch={pkg.ARCH}", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", str(out),
+                        os.path.join(pkg.CSRC, "blur_kernels.hip")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = out.read_text()
+
+    def vgprs(fragment):
+        m = re.search(r"\.amdhsa_kernel _ZN7mi_blur\d+" + fragment + r".*?\.end_amdhsa_kernel", text, re.S)
+        assert m, fragment
+        return int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(0)).group(1))
+
+    budget = {"blur_fused_kernelILi3ELi1ELi8E": (48, 64),                     # the headline kernel: 54
+              "blur_tiled_kernelILi3ELi1ELi8ELb1ELb0ELb0E": (48, 64),          # one-launch 3x3: 54
+              "blur_tiled_kernelILi3ELi1ELi4ELb1ELb0ELb0E": (48, 64),          # small grids: 53
+              "blur_direct_kernelILi3ELi2ELi8E": (80, 104),                    # 1080p 5x5: 94
+              "blur_direct_kernelILi3ELi1ELi8E": (60, 84),                     # small 3x3 launches: 70
+              "blur_server_kernelILi3ELi1ELi4ELb0E": (56, 80)}                 # zero-copy batch server: 68
+    got = {k: vgprs(k) for k in budget}
+    bad = {k: (got[k], budget[k]) for k in budget if not budget[k][0] <= got[k] <= budget[k][1]}
+    assert not bad, f"VGPR counts outside the tuned ranges (kernel: (count, (lo, hi))): {bad}"

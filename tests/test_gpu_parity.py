@@ -59,6 +59,7 @@ def reset_opts(L):
     L.mi_blur_set_option(b"zero_copy_workers", 48)
     L.mi_blur_set_option(b"zero_copy_idle_us", 300)
     L.mi_blur_set_option(b"zero_copy_budget", 256)
+    L.mi_blur_set_option(b"resident_place_trials", 4)
 
 
 def want_batch(O, host, radius):
@@ -684,6 +685,34 @@ def test_halo_pull_fills_the_halo_rows(pkg, L, O, torch_cuda, radius):
     assert L.mi_blur_halo_pull(None, None, None, 16, 3, 8, 1, None) == pkg.ERR_INVALID
     t = torch.zeros(1024, dtype=torch.uint8, device="cuda")
     assert L.mi_blur_halo_pull(t.data_ptr(), None, None, 16, 3, 8, 1, None) == pkg.OK          # no neighbour: nothing to do
+
+
+def test_resident_pool_placement_trials(pkg, L, O, torch_cuda):
+    """mi_blur_resident_alloc places big pools: it times a few candidate placements on the context's kernel and keeps the
+    fastest (where a pool lands in HBM moves big launches between two levels ~6 % apart).  The choice is reported; small pools
+    and "resident_place_trials" 0 take the first allocation; results do not depend on any of it."""
+    h, w, c, n = 256, 256, 3, 1500                        # 295 MB per buffer
+    want = None
+    for trials in (4, 2, 0):
+        pkg.check(L.mi_blur_set_option(b"resident_place_trials", trials))
+        try:
+            with pkg.Context(0, w, h, c, 1, max_batch=1, n_slots=1) as ctx:
+                ctx.resident_alloc(n)
+                pl = ctx.resident_placement()
+                assert len(pl["candidates_us"]) == (trials if trials > 1 else 0), pl
+                if trials > 1:
+                    assert 0 <= pl["kept"] < trials and min(pl["candidates_us"]) == pl["candidates_us"][pl["kept"]] > 0
+                ctx.resident_fill_synthetic(0)
+                ctx.resident_run(n, n); ctx.sync()
+                out = np.zeros((3, h, w, c), np.uint8)
+                ctx.resident_download(n - 3, out.ctypes.data, 3)
+                if want is None:
+                    want = O.blur_batch(O.lcg_stream(3, h, w, c, first_index=n - 3), 1)
+                assert np.array_equal(out, want)
+                ctx.resident_alloc(8)                      # a small pool: no trial
+                assert ctx.resident_placement()["candidates_us"] == []
+        finally:
+            pkg.check(L.mi_blur_set_option(b"resident_place_trials", 4))
 
 
 def test_submit_bands_strided_batch(pkg, L, O, torch_cuda):
