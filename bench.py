@@ -503,9 +503,9 @@ def main() -> None:
                "pcie_gbs_each_way": round(nbatches * nbytes / dte / 1e9, 1),
                "frac_of_link": round(nbatches * nbytes / dte / 1e9 / LINK_ONE_WAY_GBS, 3),
                "h2d_ms": round(te["h2d_ms"], 2), "kernel_ms": round(te["kernel_ms"], 2), "d2h_ms": round(te["d2h_ms"], 2)}
+        e2e.close()
         for (pi, po) in bufs:
             L.mi_blur_host_free(pi); L.mi_blur_host_free(po)
-        e2e.close()
         return res
 
     golden = load_golden()
