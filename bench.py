@@ -775,7 +775,8 @@ def main() -> None:
 
     fused = args.workload == "a1" and args.dispatch == "fused" and args.batch < per_gpu_images
     if args.streams <= 0:
-        args.streams = 4 if (args.workload == "a1" and not fused) else 1
+        # several streams only help small launches whose dispatch floors must overlap; one launch per pass stays on one stream
+        args.streams = 4 if (args.workload == "a1" and not fused and args.batch < per_gpu_images) else 1
     extra = {}
     other_line, other_key = None, None
     sustained = None

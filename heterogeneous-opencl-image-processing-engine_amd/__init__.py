@@ -286,9 +286,9 @@ class Context:
 
     def resident_placement(self) -> dict:
         """What resident_alloc measured when it chose the pool: per-launch us of each candidate placement, and the one kept."""
-        ms = (C.c_float * 8)()
+        ms = (C.c_float * 64)()
         kept = C.c_int()
-        n = lib().mi_blur_resident_placement(self.h, ms, 8, C.byref(kept))
+        n = lib().mi_blur_resident_placement(self.h, ms, 64, C.byref(kept))
         return {"candidates_us": [round(ms[k] * 1e3, 2) for k in range(max(n, 0))], "kept": kept.value}
 
     def resident_fill_synthetic(self, first_index: int = 0) -> None:

@@ -934,69 +934,70 @@ extern "C" int mi_blur_wait_oldest(mi_blur_ctx *c)
 // stream: 322 <-> 345 us): same request counts on every channel, but 1.5x the read DRAM-credit stalls on the slow
 // placements (profiles/r03_placement_channels.txt).  Nothing in the address says which it will be, and hipMalloc offers no
 // handle on it — but a placement keeps its level for as long as it lives, so the pool is CHOSEN: "resident_place_trials"
-// candidate (in, out) pairs are allocated side by side, each is timed on the launch the pool is for (the context's kernel
-// over the whole pool, timings interleaved and after a clock ramp), the fastest is kept and the others are freed.
+// candidate inputs and as many candidate outputs are allocated side by side, every (input, output) pair is timed on the
+// launch the pool is for (the context's kernel over the whole pool, after a clock ramp), the fastest pair is kept and the
+// other buffers are freed.
 static int place_pool(mi_blur_ctx *c, size_t bytes, int pool_images, int trials)
 {
-    struct Cand { uint8_t *in = nullptr, *out = nullptr; float best_ms = 1e30f; };
-    std::vector<Cand> cand((size_t)trials);
-    auto release = [&](int keep) {
-        for (int i = 0; i < trials; i++) {
-            if (i == keep) continue;
-            if (cand[i].in) (void)hipFree(cand[i].in);
-            if (cand[i].out) (void)hipFree(cand[i].out);
-        }
-    };
+    // `trials` input and `trials` output candidates; EVERY (input, output) pair is timed — the level belongs to the pair, and
+    // n + n buffers give n x n pairs to choose from for the price of n.
+    std::vector<uint8_t *> in((size_t)trials, nullptr), out((size_t)trials, nullptr);
     int n_ok = 0;
     for (int i = 0; i < trials; i++) {
-        if (hipMalloc((void **)&cand[i].in, bytes) != hipSuccess || hipMalloc((void **)&cand[i].out, bytes) != hipSuccess) {
+        if (hipMalloc((void **)&in[i], bytes) != hipSuccess || hipMalloc((void **)&out[i], bytes) != hipSuccess) {
             (void)hipGetLastError();
-            if (cand[i].in) { (void)hipFree(cand[i].in); cand[i].in = nullptr; }
+            if (in[i]) { (void)hipFree(in[i]); in[i] = nullptr; }
             break;                                              // memory is short: choose among what there is
         }
         n_ok++;
     }
     if (n_ok == 0) return MI_BLUR_ERR_HIP_BASE - (int)hipErrorOutOfMemory;
     c->place_ms.clear();
-    int keep = 0;
+    int keep_in = 0, keep_out = 0;
     if (n_ok > 1) {
         hipStream_t st = c->slots[0].stream;
         hipEvent_t e0 = nullptr, e1 = nullptr;
+        std::vector<float> best((size_t)n_ok * n_ok, 1e30f);
         if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
-            auto pass = [&](Cand &k) {
+            auto pass = [&](int i, int j) {
                 LaunchDesc d{};
-                d.in = k.in; d.out = k.out; d.width = c->W; d.band_rows = c->H; d.channels = c->C; d.radius = c->R;
+                d.in = in[i]; d.out = out[j]; d.width = c->W; d.band_rows = c->H; d.channels = c->C; d.radius = c->R;
                 d.n_images = pool_images; d.y0 = 0; d.y1 = c->H; d.variant = MI_BLUR_VARIANT_AUTO; d.stream = st;
                 return launch(d);
             };
             int rc = MI_BLUR_OK;
             const auto t0 = std::chrono::steady_clock::now();      // ~50 ms of launches first: the clocks ramp (r02_clock_ramp.txt)
             while (rc == MI_BLUR_OK && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(50)) {
-                for (int r = 0; r < 4 && rc == MI_BLUR_OK; r++) rc = pass(cand[0]);
+                for (int r = 0; r < 4 && rc == MI_BLUR_OK; r++) rc = pass(0, 0);
                 if (hipStreamSynchronize(st) != hipSuccess) rc = MI_BLUR_ERR_STATE;
             }
-            for (int round = 0; round < 3 && rc == MI_BLUR_OK; round++)
-                for (int i = 0; i < n_ok && rc == MI_BLUR_OK; i++) {
-                    rc = pass(cand[i]);                             // one untimed launch: this candidate's lines and TLB entries
-                    (void)hipEventRecord(e0, st);
-                    for (int r = 0; r < 3 && rc == MI_BLUR_OK; r++) rc = pass(cand[i]);
-                    (void)hipEventRecord(e1, st);
-                    float ms = 0.f;
-                    if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.f)
-                        cand[i].best_ms = std::min(cand[i].best_ms, ms / 3.0f);
-                }
+            for (int round = 0; round < 2 && rc == MI_BLUR_OK; round++)
+                for (int i = 0; i < n_ok && rc == MI_BLUR_OK; i++)
+                    for (int j = 0; j < n_ok && rc == MI_BLUR_OK; j++) {
+                        rc = pass(i, j);                            // one untimed launch: this pair's lines and TLB entries
+                        (void)hipEventRecord(e0, st);
+                        for (int r = 0; r < 2 && rc == MI_BLUR_OK; r++) rc = pass(i, j);
+                        (void)hipEventRecord(e1, st);
+                        float ms = 0.f;
+                        if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.f)
+                            best[(size_t)i * n_ok + j] = std::min(best[(size_t)i * n_ok + j], ms / 2.0f);
+                    }
             (void)hipGetLastError();
-            for (int i = 0; i < n_ok; i++) {
-                c->place_ms.push_back(cand[i].best_ms);
-                if (cand[i].best_ms < cand[keep].best_ms) keep = i;
-            }
+            for (int i = 0; i < n_ok; i++)
+                for (int j = 0; j < n_ok; j++) {
+                    c->place_ms.push_back(best[(size_t)i * n_ok + j]);
+                    if (best[(size_t)i * n_ok + j] < best[(size_t)keep_in * n_ok + keep_out]) { keep_in = i; keep_out = j; }
+                }
         }
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
     }
-    c->pool_in = cand[keep].in; c->pool_out = cand[keep].out;
-    c->place_kept = keep;
-    release(keep);
+    c->pool_in = in[keep_in]; c->pool_out = out[keep_out];
+    c->place_kept = keep_in * n_ok + keep_out;
+    for (int i = 0; i < trials; i++) {
+        if (i != keep_in && in[i]) (void)hipFree(in[i]);
+        if (i != keep_out && out[i]) (void)hipFree(out[i]);
+    }
     return MI_BLUR_OK;
 }
 

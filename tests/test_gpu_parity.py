@@ -699,9 +699,9 @@ def test_resident_pool_placement_trials(pkg, L, O, torch_cuda):
             with pkg.Context(0, w, h, c, 1, max_batch=1, n_slots=1) as ctx:
                 ctx.resident_alloc(n)
                 pl = ctx.resident_placement()
-                assert len(pl["candidates_us"]) == (trials if trials > 1 else 0), pl
+                assert len(pl["candidates_us"]) == (trials * trials if trials > 1 else 0), pl      # every (input, output) pair
                 if trials > 1:
-                    assert 0 <= pl["kept"] < trials and min(pl["candidates_us"]) == pl["candidates_us"][pl["kept"]] > 0
+                    assert 0 <= pl["kept"] < trials * trials and min(pl["candidates_us"]) == pl["candidates_us"][pl["kept"]] > 0
                 ctx.resident_fill_synthetic(0)
                 ctx.resident_run(n, n); ctx.sync()
                 out = np.zeros((3, h, w, c), np.uint8)
