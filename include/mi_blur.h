@@ -277,9 +277,10 @@ int mi_blur_interleaved_to_planar(const uint8_t *d_interleaved, uint8_t *d_plana
 /* Pools of 128 MiB .. 8 GiB are PLACED: where a pool lands in HBM moves the big launches between two levels ~6 % apart
  * (profiles/r03_placement_channels.txt: same requests per channel, 1.5x the read DRAM-credit stalls on the slow placements),
  * nothing in the address tells which, and a placement keeps its level while it lives — so "resident_place_trials" (default 4;
- * MI_BLUR_PLACE_TRIALS in the environment; 0/1 = off) candidate (in, out) pairs are allocated side by side, each is timed on
- * the context's kernel over the whole pool (after a clock ramp, interleaved), the fastest is kept, the others are freed
- * (~0.1 s, once per pool).  mi_blur_resident_placement reports the candidates' per-launch ms and which one was kept. */
+ * MI_BLUR_PLACE_TRIALS in the environment; 0/1 = off) candidate inputs and as many candidate outputs are allocated side by
+ * side, every (input, output) pair is timed on the context's kernel over the whole pool (after a clock ramp), the fastest
+ * pair is kept, the other buffers are freed (~0.15 s, once per pool).  mi_blur_resident_placement reports the pairs'
+ * per-launch ms (row-major: input i, output j at i*n + j) and which one was kept. */
 int mi_blur_resident_alloc(mi_blur_ctx *ctx, int pool_images);
 int mi_blur_resident_placement(mi_blur_ctx *ctx, float *ms, int max_n, int *kept);
 /* Fill pool image i with the synthetic LCG image (seed 0x9E3779B9 ^ (first_index+i)). */
