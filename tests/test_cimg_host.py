@@ -78,6 +78,26 @@ def test_cimg_lossless_round_trip_through_the_blur(cimg_hosts, O, tmp_path):
         assert np.array_equal(read_image(tmp_path / "out.bmp"), O.blur(img, radius))  # ... blur ... interleaved->planar + save
 
 
+def test_cimg_frames_stream(cimg_hosts, O, tmp_path):
+    """--frames in the CImg build: every frame is decoded by CImg — whose storage IS planar, so the decode is the planar
+    batch buffer — blurred (cpu device here) and saved through CImg as BMP; interleaved and planar output, 3x3 and 5x5.
+    Every saved frame == oracle blur of its own input."""
+    exes, _ = cimg_hosts
+    frames = O.lcg_stream(9, 36, 52, 3, first_index=700)
+    os.makedirs(tmp_path / "in")
+    for i in range(len(frames)):
+        write_ppm(tmp_path / "in" / f"f_{i:03d}.ppm", frames[i])
+    for extra, ksize, radius, outdir in (([], "3", 1, "o1"), (["--planar-out"], "5", 2, "o2")):
+        r = subprocess.run([exes["heterogeneous_blur"], "cpu", "0.5", "4", "--frames", "in", "--save-dir", outdir, "--ksize", ksize] + extra,
+                           cwd=tmp_path, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "10. FRAME INGEST" in r.stdout, r.stdout + r.stderr
+        want = O.blur_batch(frames, radius)
+        for i in range(len(frames)):
+            assert np.array_equal(read_image(tmp_path / outdir / f"f_{i:03d}.bmp"), want[i]), (i, extra)
+    r = subprocess.run([exes["heterogeneous_blur"], "cpu", "0.5", "4", "--frames", "in", "--native-layout"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "--native-layout ignored in a CImg build" in r.stdout
+
+
 def test_cimg_jpeg_input_is_the_reference_default(cimg_hosts, O, golden, tmp_path):
     """The reference's default input (`./image_320x240.jpg`, heterogeneous_blur.c:43) decoded by CImg + libjpeg as the
     reference does: the host picks it up from the CWD with NO --image flag; blur(decoded input) == saved output bit for
