@@ -1159,7 +1159,7 @@ def main() -> None:
             hh, ww, cc, rr = base_shape
             if args.workload == "a2":
                 hh, ww = 1024, 8192           # a band-sized slice of the same image keeps the sample bounded
-            line["cpu_baseline"] = cpu_baseline(5000 if args.workload == "a1" else 64, hh, ww, cc, rr)
+            line["cpu_baseline"] = guarded("cpu_baseline", lambda: cpu_baseline(5000 if args.workload == "a1" else 64, hh, ww, cc, rr))
         if sustained:
             line["sustained_img_s"] = sustained["img_s"]
             line["sustained"] = sustained
