@@ -139,15 +139,22 @@ int main(int argc, char **argv)
         printf("CPU device: %s\n", cpu.name.c_str());
         cpu.submitted.assign(NUM_BATCHES, 0);
     }
+    // gpu mode from host buffers: one feeder thread per GPU, each with its own buffers, placed on the GPU's socket.  A big
+    // batch (the reference's default is 500) is built and handed over in up to 4 pieces, so that building the rest of a
+    // batch overlaps the transfer of its first piece: the batch stays the unit the buffers rotate by (and of the report),
+    // a piece is the unit of submission.
+    const bool per_gpu_feeders = mode == 2 && !opt.resident;
+    const int share_max = G > 0 ? (BATCH_SIZE + G - 1) / G : BATCH_SIZE;      // the largest contiguous share of a batch (mi_blur_shard_range)
+    const int feed_pieces = per_gpu_feeders ? std::max(1, std::min(4, (share_max + 63) / 64)) : 1;
+    const int feed_piece = (share_max + feed_pieces - 1) / feed_pieces;
     for (int g = 0; g < G; g++) {
-        mi_check(mi_blur_create(&gpus[g].ctx, hip_ordinal(g), width, height, channels, radius, BATCH_SIZE, nslots, 0),
+        mi_check(per_gpu_feeders ? mi_blur_create(&gpus[g].ctx, hip_ordinal(g), width, height, channels, radius, feed_piece, nslots * feed_pieces, 0)
+                                 : mi_blur_create(&gpus[g].ctx, hip_ordinal(g), width, height, channels, radius, BATCH_SIZE, nslots, 0),
                  "Failed to create GPU context");
         gpus[g].name = "HIP device " + std::to_string(hip_ordinal(g)) + (virtual_gpus() ? " (logical GPU " + std::to_string(g) + ")" : "");
         printf("GPU device: %s\n", gpus[g].name.c_str());
         gpus[g].submitted.assign(NUM_BATCHES, 0);
     }
-    // gpu mode from host buffers: one feeder thread per GPU, each with its own buffers, placed on the GPU's socket
-    const bool per_gpu_feeders = mode == 2 && !opt.resident;
     for (int g = 0; g < G; g++) report_placement(g, hip_ordinal(g), /*bind the calling thread*/ !per_gpu_feeders && g == 0);
     printf("\nKernel objects created (code objects are embedded in libmi_blur.so; nothing is read from the CWD)\n\n");
 
@@ -157,7 +164,7 @@ int main(int argc, char **argv)
     std::vector<std::vector<uint8_t *>> gin(G), gout(G);               // per_gpu_feeders: GPU g's own rotating buffer sets
     if (per_gpu_feeders) {
         for (int g = 0; g < G; g++) {
-            const size_t share = (size_t)(BATCH_SIZE + G - 1) / G;     // the largest contiguous share of a batch (mi_blur_shard_range)
+            const size_t share = (size_t)share_max;
             for (int s = 0; s < nslots; s++) {
                 gin[g].push_back((uint8_t *)mi_blur_host_alloc_on(hip_ordinal(g), share * image_size));
                 gout[g].push_back((uint8_t *)mi_blur_host_alloc_on(hip_ordinal(g), share * image_size));
@@ -249,7 +256,8 @@ int main(int argc, char **argv)
                 }
                 at_gate.fetch_add(1);
                 while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
-                long long k = 0;                                      // this feeder's submits so far
+                long long k = 0;                                      // this feeder's batches so far
+                std::vector<int> pieces_of(nslots, 0);                // how many submits the batch in buffer set s was handed over in
                 for (int batch = 0; batch < NUM_BATCHES && feed_rc[g] == MI_BLUR_OK; batch++) {
                     const int batch_start = batch * BATCH_SIZE;
                     const int batch_count = std::min(BATCH_SIZE, NUM_IMAGES - batch_start);
@@ -259,13 +267,20 @@ int main(int argc, char **argv)
                     if (g == 0 && opt.verbose) printf("=== Processing Batch %d/%d === (GPU 0 share: %d images)\n", batch + 1, NUM_BATCHES, n);
                     if (n <= 0) continue;
                     const int s = (int)(k % nslots);
-                    if (k >= nslots) {                                // the buffer set was last used by submit k - nslots
-                        if (!ok(mi_blur_wait_oldest(ctx))) break;
+                    if (k >= nslots) {                                // the buffer set was last used by batch k - nslots: all its pieces
+                        for (int q = 0; q < pieces_of[s] && feed_rc[g] == MI_BLUR_OK; q++) ok(mi_blur_wait_oldest(ctx));
+                        if (feed_rc[g] != MI_BLUR_OK) break;
                         if (g == 0 && opt.save.size() && first_output.empty() && k == nslots)
                             first_output.assign(gout[0][0], gout[0][0] + image_size);
                     }
-                    rep.run(gin[g][s], original_image, image_size, n);       // create batch image stream (:439-442)
-                    if (!ok(mi_blur_submit(ctx, gin[g][s], gout[g][s], n))) break;
+                    int done = 0, pieces = 0;
+                    while (done < n && feed_rc[g] == MI_BLUR_OK) {     // create batch image stream (:439-442) and hand it over, piece by piece
+                        const int m = std::min(feed_piece, n - done);
+                        rep.run(gin[g][s] + (size_t)done * image_size, original_image, image_size, m);
+                        ok(mi_blur_submit(ctx, gin[g][s] + (size_t)done * image_size, gout[g][s] + (size_t)done * image_size, m));
+                        done += m; pieces++;
+                    }
+                    pieces_of[s] = pieces;
                     k++;
                 }
                 ok(mi_blur_sync(ctx, &gpus[g].tm));                     // clFinish (:538-539)
