@@ -679,6 +679,12 @@ def main() -> None:
 
             forms["pull"] = step_pull
 
+            def step_peer():       # the whole step as ONE launch: the band kernel reads the neighbours' rows in place
+                pkg.check(L.mi_blur_enqueue_band_peer(band.data_ptr(), out.data_ptr(), Wd, rows, c, radius, ht, ht + owned,
+                                                      top_src or None, bottom_src or None, stream), "enqueue_band_peer")
+
+            forms["peer"] = step_peer
+
         # untimed ramp past the ~40 ms clock ramp that follows any idle gap.  A FIXED step count, the same on every rank:
         # each step holds a send/recv pair, so ranks must not decide by their own clocks how many to run.
         ramp_steps = int(ramp_seconds * 1e6 / 100.0)
@@ -698,7 +704,7 @@ def main() -> None:
             # every form starts from poisoned halo rows, so its OWN exchange is what the band hash proves (rehearsal: the two
             # RCCL forms get the rows uploaded instead, as their exchange is left out; the pull form is real there as well)
             if world > 1:
-                if fake_exchange and fname != "pull":
+                if fake_exchange and fname not in ("pull", "peer"):
                     band[:ht * pitch] = halo_rows_host[0]
                     band[(ht + owned) * pitch:] = halo_rows_host[1]
                 else:
@@ -731,9 +737,10 @@ def main() -> None:
             elif fnv != want:
                 parity["ok"] = False
                 parity["expected"] = want
-            timed[fname] = {"elapsed": el, "local": loc, "step_us": round(el / K2 * 1e6, 2), "stream_us": ev0.elapsed_time(ev1) * 1e3 / K2}
-        kernel_name = L.mi_blur_last_kernel().decode()
+            timed[fname] = {"elapsed": el, "local": loc, "step_us": round(el / K2 * 1e6, 2), "stream_us": ev0.elapsed_time(ev1) * 1e3 / K2,
+                            "kernel": L.mi_blur_last_kernel().decode()}
         quoted = min(timed, key=lambda k: timed[k]["elapsed"])
+        kernel_name = timed[quoted]["kernel"]
         bytes_per_launch = 2.0 * owned * pitch
 
         # ---- per-step decomposition (outside the timed regions): exchange vs band kernel on this rank's stream
@@ -768,8 +775,11 @@ def main() -> None:
         config = {"workload": f"one 8192x8192x3 image per step, 3x3, row-split over {world} GPU(s), RCCL halo exchange [BASELINE configs[4]]",
                   "rows_per_gpu": owned, "halo_bytes_per_neighbour": radius * pitch, "ramp_steps": ramp_steps,
                   "steps_per_form": K2, "step_forms_us": {k: v["step_us"] for k, v in timed.items()}, "quoted_form": quoted,
-                  "rccl_step_us": min(v["step_us"] for k, v in timed.items() if k != "pull"),
+                  "rccl_step_us": min(v["step_us"] for k, v in timed.items() if k not in ("pull", "peer")),
                   "pull_form": ("halo rows pulled out of the neighbours' shards by one copy kernel reading peer memory (IPC-mapped)"
+                                if pull_ok else f"not run: {pull_note or 'one rank'}"),
+                  "peer_form": ("one launch per step: the band kernel reads its halo rows in place from the neighbours' shards "
+                                "(IPC-mapped peer memory); this shard's own halo rows stay poisoned"
                                 if pull_ok else f"not run: {pull_note or 'one rank'}"),
                   "rccl_ranks": comm_ranks if comm_transport == 1 else 0,
                   "halo_transport": {0: "none (one rank: both image edges clamp)", 1: "RCCL ncclSend/ncclRecv", 2: "peer copies"}[comm_transport],

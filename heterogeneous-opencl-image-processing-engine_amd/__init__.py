@@ -179,6 +179,7 @@ def lib() -> C.CDLL:
         "mi_blur_peer_open": (i, [vp, C.c_uint64, C.POINTER(vp)]),
         "mi_blur_peer_close": (i, [vp, C.c_uint64]),
         "mi_blur_halo_pull": (i, [u8p, u8p, u8p, i, i, i, i, vp]),
+        "mi_blur_enqueue_band_peer": (i, [u8p, u8p, i, i, i, i, i, i, u8p, u8p, vp]),
         "mi_blur_halo_exchange_all": (i, [C.POINTER(vp), i, C.POINTER(vp), i, i, C.POINTER(i), i, C.POINTER(vp)]),
     }
     for name, (res, args) in sig.items():

@@ -175,7 +175,7 @@ struct Options {
                                          //              batches counted in as they finish (mi_blur_resident_run_fused)
     bool overlap = false;                // --overlap    (split_image_blur --resident): halo exchange on its own stream, hidden
                                          //              behind the blur of the interior rows; edge rows follow it
-    std::string transport = "rccl";      // --transport rccl|p2p|pull  (split_image_blur --resident): halo rows by RCCL, pushed peer copies,
+    std::string transport = "rccl";      // --transport rccl|p2p|pull|peer  (split_image_blur --resident): halo rows by RCCL, pushed peer copies,
                                          //              or pulled by one small kernel per GPU that reads its neighbours' rows
     bool auto_ratio = false;             // gpu_ratio given as "auto": calibrate on the first batches (heterogeneous_blur both)
     bool size_given = false;
@@ -222,7 +222,7 @@ inline int parse_flags(int argc, char **argv, Options &o)
         else if (a == "--save-dir") o.save_dir = next("--save-dir");
         else if (a == "--planar-out") o.planar_out = true;
         else if (a == "--native-layout") o.native_layout = true;
-        else if (a == "--transport") { o.transport = next("--transport"); if (o.transport != "rccl" && o.transport != "p2p" && o.transport != "pull") { printf("Error: --transport rccl|p2p|pull\n"); exit(-1); } }
+        else if (a == "--transport") { o.transport = next("--transport"); if (o.transport != "rccl" && o.transport != "p2p" && o.transport != "pull" && o.transport != "peer") { printf("Error: --transport rccl|p2p|pull|peer\n"); exit(-1); } }
         else { printf("Error: unknown option %s\n", a.c_str()); exit(-1); }
     }
     return npos;

@@ -3,7 +3,7 @@
 //   split_image_blur [gpu_ratio] [batch]  [--image F | --synthetic | --size WxH] [--channels C] [--ksize 3|5]
 //                    [--images N] [--gpus G] [--slots S] [--threads T] [--verbose] [--csv FILE] [--save FILE]
 //   split_image_blur --resident [--gpus G] [--size WxH] [--ksize 3|5] [--iters N] [--iterate] [--overlap]
-//                    [--transport rccl|p2p] [--save FILE]
+//                    [--transport rccl|p2p|pull|peer] [--save FILE]
 //
 // Default mode keeps the reference host's semantics (split_image_blur.c:62-102 CLI, :142-173
 // geometry, :441-607 batch loop, :615-721 report): every image is split at
@@ -249,14 +249,18 @@ static int run_resident(const Options &opt)
     const int W = opt.size_given ? opt.syn_w : 8192, H = opt.size_given ? opt.syn_h : 8192, C = opt.syn_c;
     const size_t pitch = (size_t)W * C;
     if (!gpus_available(G)) { printf("Error: %d GPU(s) asked, %d visible\n", G, mi_blur_device_count()); return -1; }
-    const bool pull = opt.transport == "pull";
+    // peer: no exchange at all — the band kernel reads the neighbours' rows where they lie (mi_blur_enqueue_band_peer); the
+    // communicator of the pull transport is still made, for the peer access it enables between the devices
+    const bool peer = opt.transport == "peer";
+    const bool pull = opt.transport == "pull" || peer;
     const bool p2p = opt.transport == "p2p" || (virtual_gpus() && !pull);      // RCCL refuses two ranks on one device
+    if (peer && (pitch % 16 || C > 4)) { printf("Error: --transport peer needs rows of whole 16-byte chunks and 1-4 channels\n"); return -1; }
     if (H / G < radius) { printf("Error: shards of %d rows are thinner than the halo\n", H / G); return -1; }
     printf("========== SPLIT-IMAGE (RESIDENT, MULTI-GPU) ==========\n");
     printf("Image: %dx%d, %d channels (%.2f MB), %dx%d blur, %d GPU(s), %d iterations\n", W, H, C, pitch * H / 1e6, opt.ksize,
            opt.ksize, G, opt.iters);
     printf("Halo: %d row(s) = %zu bytes per neighbour per direction, %s\n\n", radius, radius * pitch,
-           pull ? "pulled by one kernel per GPU (peer reads)" : p2p ? "hipMemcpyPeerAsync pushes" : "RCCL send/recv");
+           peer ? "read in place by the band kernel (peer reads, no exchange step)" : pull ? "pulled by one kernel per GPU (peer reads)" : p2p ? "hipMemcpyPeerAsync pushes" : "RCCL send/recv");
 
     std::vector<uint8_t> image(pitch * H);
     mi_blur_fill_synthetic(image.data(), W, H, C, 0, 1, 0);
@@ -273,7 +277,7 @@ static int run_resident(const Options &opt)
         HIP_OK(hipStreamCreateWithFlags(&stream[g], hipStreamNonBlocking));
         HIP_OK(hipMalloc((void **)&d_band[g], rows * pitch));
         HIP_OK(hipMalloc((void **)&d_out[g], (size_t)owned[g] * pitch));
-        HIP_OK(hipMemset(d_band[g], 0, rows * pitch));
+        HIP_OK(hipMemset(d_band[g], peer ? 0xA5 : 0, rows * pitch));     // peer: the shard's own halo rows stay this poison, unread
         // upload OWNED rows only: the halo rows arrive from the neighbours over xGMI
         HIP_OK(hipMemcpy(d_band[g] + (size_t)band[g].halo_top * pitch, image.data() + (size_t)band[g].row_begin * pitch,
                          (size_t)owned[g] * pitch, hipMemcpyHostToDevice));
@@ -292,7 +296,7 @@ static int run_resident(const Options &opt)
             HIP_OK(hipSetDevice(devs[g]));
             const size_t rows = owned[g] + band[g].halo_top + band[g].halo_bottom;
             HIP_OK(hipMalloc((void **)&d_band2[g], rows * pitch));
-            HIP_OK(hipMemset(d_band2[g], 0, rows * pitch));
+            HIP_OK(hipMemset(d_band2[g], peer ? 0xA5 : 0, rows * pitch));
         }
     auto upload = [&]() {
         for (int g = 0; g < G; g++) {
@@ -307,7 +311,7 @@ static int run_resident(const Options &opt)
     // ev_halo[g] = this step's halos of GPU g are in place.
     std::vector<hipStream_t> xstream(G, nullptr);
     std::vector<hipEvent_t> ev_done(G, nullptr), ev_halo(G, nullptr);
-    bool can_overlap = G > 1;
+    bool can_overlap = G > 1 && !peer;                   // nothing to overlap when there is no exchange
     for (int g = 0; g < G && can_overlap; g++) if (owned[g] <= 2 * radius) can_overlap = false;     // no interior to hide behind
     bool overlap = opt.overlap && can_overlap;
     if (can_overlap)      // set up even when not asked for: the report times both forms side by side (below)
@@ -344,7 +348,34 @@ static int run_resident(const Options &opt)
         }
         if (opt.iterate) std::swap(d_band, d_band2);
     };
+    // peer transport: one launch per GPU per step.  Only an iterated blur needs ordering between the GPUs (a shard's rows
+    // change from step to step): a GPU starts step i+1 once both neighbours have finished step i — their new rows are final,
+    // and they are done reading the rows this GPU is about to overwrite.
+    std::vector<hipEvent_t> ev_step(G, nullptr);
+    if (peer)
+        for (int g = 0; g < G; g++) { HIP_OK(hipSetDevice(devs[g])); HIP_OK(hipEventCreateWithFlags(&ev_step[g], hipEventDisableTiming)); }
+    auto step_peer = [&]() {
+        if (opt.iterate)
+            for (int g = 0; g < G; g++) { HIP_OK(hipSetDevice(devs[g])); HIP_OK(hipEventRecord(ev_step[g], stream[g])); }
+        for (int g = 0; g < G; g++) {
+            HIP_OK(hipSetDevice(devs[g]));
+            const uint8_t *top = nullptr, *bottom = nullptr;
+            if (g > 0) {
+                if (opt.iterate) HIP_OK(hipStreamWaitEvent(stream[g], ev_step[g - 1], 0));
+                top = d_band[g - 1] + (size_t)(band[g - 1].halo_top + owned[g - 1] - radius) * pitch;
+            }
+            if (g < G - 1) {
+                if (opt.iterate) HIP_OK(hipStreamWaitEvent(stream[g], ev_step[g + 1], 0));
+                bottom = d_band[g + 1] + (size_t)band[g + 1].halo_top * pitch;
+            }
+            uint8_t *dst = opt.iterate ? d_band2[g] + (size_t)band[g].halo_top * pitch : d_out[g];
+            mi_check(mi_blur_enqueue_band_peer(d_band[g], dst, W, owned[g] + band[g].halo_top + band[g].halo_bottom, C, radius,
+                                               band[g].halo_top, band[g].halo_top + owned[g], top, bottom, stream[g]), "band launch failed");
+        }
+        if (opt.iterate) std::swap(d_band, d_band2);
+    };
     auto step = [&]() {
+        if (peer) { step_peer(); return; }
         if (overlap) { step_overlapped(); return; }
         std::vector<void *> st(G);
         for (int g = 0; g < G; g++) st[g] = stream[g];
@@ -412,7 +443,8 @@ static int run_resident(const Options &opt)
     // the band kernel each occupy a GPU's stream, and — when shards have an interior — the same step issued plain and
     // with the exchange hidden behind the interior rows.  On real xGMI this says whether RCCL latency or the three-launch
     // overlapped form bounds a step.  Skipped with --iterate (extra steps would advance the blur chain).
-    if (!opt.iterate) {
+    if (peer) printf("   Per-step decomposition: none — a step is one launch per GPU (the halo rows cross the link inside the band kernel's loads)\n");
+    if (!opt.iterate && !peer) {
         const int n = std::max(1, std::min(opt.iters, 50));
         std::vector<hipEvent_t> ea(G), eb(G), ec(G);
         for (int g = 0; g < G; g++) {
@@ -466,6 +498,7 @@ static int run_resident(const Options &opt)
         mi_blur_comm_destroy(comm[g]);
         HIP_OK(hipFree(d_band[g])); HIP_OK(hipFree(d_out[g])); HIP_OK(hipStreamDestroy(stream[g]));
         if (d_band2[g]) HIP_OK(hipFree(d_band2[g]));
+        if (ev_step[g]) HIP_OK(hipEventDestroy(ev_step[g]));
         if (xstream[g]) { HIP_OK(hipStreamDestroy(xstream[g])); HIP_OK(hipEventDestroy(ev_done[g])); HIP_OK(hipEventDestroy(ev_halo[g])); }
     }
     return same ? 0 : 1;

@@ -992,9 +992,12 @@ struct DirectParams {
     int nbands;
     unsigned nblocks;
     int xcd;
+    const uint8_t *top, *bottom;      // PEER: where band rows [0, y0) / [y1, H) are read instead (nullptr = from the band itself)
 };
 
-template <int C, int R, int BH>
+// PEER (one band per launch, Approach 2 across GPUs): the halo rows above/below the output rows are read where they live —
+// in the neighbouring ranks' shards, over xGMI — so a step is this one launch: no exchange, no copy, no halo rows kept.
+template <int C, int R, int BH, bool PEER = false>
 __global__ __launch_bounds__(256) void blur_direct_kernel(const DirectParams p)
 {
     constexpr int WIN = 2 * R + 1, NR = BH + 2 * R;
@@ -1015,9 +1018,23 @@ __global__ __launch_bounds__(256) void blur_direct_kernel(const DirectParams p)
     uint8_t *dst = p.out + img * p.out_stride + (size_t)(row0 - p.y0) * (size_t)p.pitch + (size_t)col * 16u;
 
     uint4 rows[NR];
+    // PEER: only the first and last lane bands of the shard reach outside [y0, y1); every other wave takes the plain loop
+    bool outside = false;
+    if constexpr (PEER) outside = __builtin_amdgcn_ballot_w64(row0 - R < p.y0 || row0 + BH + R > p.y1) != 0ull;
+    if (outside) {
 #pragma unroll
-    for (int j = 0; j < NR; j++)
-        rows[j] = *reinterpret_cast<const uint4 *>(src + (size_t)min(max(row0 - R + j, 0), p.H - 1) * (size_t)p.pitch);
+        for (int j = 0; j < NR; j++) {
+            const int sr = min(max(row0 - R + j, 0), p.H - 1);
+            const uint8_t *rp = src + (size_t)sr * (size_t)p.pitch;
+            if (sr < p.y0 && p.top) rp = p.top + (size_t)col * 16u + (size_t)sr * (size_t)p.pitch;
+            if (sr >= p.y1 && p.bottom) rp = p.bottom + (size_t)col * 16u + (size_t)(sr - p.y1) * (size_t)p.pitch;
+            rows[j] = *reinterpret_cast<const uint4 *>(rp);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NR; j++)
+            rows[j] = *reinterpret_cast<const uint4 *>(src + (size_t)min(max(row0 - R + j, 0), p.H - 1) * (size_t)p.pitch);
+    }
 
     uint32_t hw[WIN][8];
 #pragma unroll
@@ -1522,6 +1539,23 @@ static int launch_direct_bh(const LaunchDesc &d, const Tunables &tun)
     p.nblocks = (unsigned)nblocks;
     p.xcd = (tun.xcd_remap && nblocks >= 16) ? 1 : 0;
     const dim3 grid((unsigned)nblocks), block(256);
+    if (d.halo_top || d.halo_bottom) {
+        if constexpr (BH == 8) {
+            p.top = d.halo_top; p.bottom = d.halo_bottom;
+            g_last_kernel = "blur_direct_kernel (peer halo rows)";
+            switch (d.channels * 10 + d.radius) {
+            case 11: return do_launch(blur_direct_kernel<1, 1, 8, true>, grid, block, 0, d, p);
+            case 12: return do_launch(blur_direct_kernel<1, 2, 8, true>, grid, block, 0, d, p);
+            case 21: return do_launch(blur_direct_kernel<2, 1, 8, true>, grid, block, 0, d, p);
+            case 22: return do_launch(blur_direct_kernel<2, 2, 8, true>, grid, block, 0, d, p);
+            case 31: return do_launch(blur_direct_kernel<3, 1, 8, true>, grid, block, 0, d, p);
+            case 32: return do_launch(blur_direct_kernel<3, 2, 8, true>, grid, block, 0, d, p);
+            case 41: return do_launch(blur_direct_kernel<4, 1, 8, true>, grid, block, 0, d, p);
+            case 42: return do_launch(blur_direct_kernel<4, 2, 8, true>, grid, block, 0, d, p);
+            }
+        }
+        return MI_BLUR_ERR_INVALID;
+    }
     if constexpr (BH != 8) {
         return d.radius == 1 ? do_launch(blur_direct_kernel<3, 1, BH>, grid, block, 0, d, p)
                              : do_launch(blur_direct_kernel<3, 2, BH>, grid, block, 0, d, p);
@@ -1571,6 +1605,15 @@ int launch(const LaunchDesc &d)
     const long long row_bytes = (long long)d.width * d.channels;
     const bool can_tile = wide ? (row_bytes % 16 == 0 && (uintptr_t)d.in % 16 == 0 && (uintptr_t)d.out % 16 == 0)
                                : tiled_eligible(d.in, d.out, d.width, d.channels);
+    if (d.halo_top || d.halo_bottom) {
+        // halo rows read in place from other shards: one dense band, the direct kernel's shapes (rows of whole 16-byte chunks)
+        if (d.n_images != 1 || d.in_stride || d.out_stride || d.max_blocks > 0) return MI_BLUR_ERR_INVALID;
+        if ((uintptr_t)d.halo_top % 16 || (uintptr_t)d.halo_bottom % 16) return MI_BLUR_ERR_INVALID;
+        if (d.variant != MI_BLUR_VARIANT_AUTO && d.variant != MI_BLUR_VARIANT_DIRECT) return MI_BLUR_ERR_UNSUPPORTED;
+        if (!can_tile || wide || !direct_fits(d)) return MI_BLUR_ERR_UNSUPPORTED;
+        Tunables t8 = tun; t8.direct_bh = 8;
+        return launch_direct(d, t8);
+    }
     const long long dense_in = (long long)d.band_rows * d.width * d.channels, dense_out = (long long)(d.y1 - d.y0) * d.width * d.channels;
     if ((d.in_stride && d.in_stride != dense_in) || (d.out_stride && d.out_stride != dense_out)) {
         // spaced-out bands (a caller's buffer used in place): tiled kernel only

@@ -18,6 +18,8 @@ struct LaunchDesc {
                             // Small 3x3 launches that overlap with their like run faster as LDS tiles, alone as the direct kernel.
     int max_blocks;         // > 0: cap the grid of the aligned tiled kernel; its workgroups then loop over the tiles (zero-copy submits)
     int variant;            // mi_blur_variant
+    const uint8_t *halo_top, *halo_bottom;   // one band only: rows [0, y0) / [y1, band_rows) are read from here (another shard,
+                            // possibly another GPU's memory) instead of from `in`; nullptr = from `in`.  Direct kernel only.
     hipStream_t stream;
     hipEvent_t start, stop; // optional: dispatch start/stop timestamps (hipExtLaunchKernel)
 };

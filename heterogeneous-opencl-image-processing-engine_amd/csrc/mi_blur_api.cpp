@@ -144,6 +144,22 @@ extern "C" int mi_blur_enqueue_band(const uint8_t *d_in, uint8_t *d_out, int wid
                               MI_BLUR_VARIANT_AUTO, stream);
 }
 
+// Band whose halo rows are read in place from the neighbouring shards (peer memory): exchange and blur in one launch.
+extern "C" int mi_blur_enqueue_band_peer(const uint8_t *d_in, uint8_t *d_out, int width, int band_rows, int channels,
+                                         int radius, int out_row_begin, int out_row_end, const uint8_t *top_src,
+                                         const uint8_t *bottom_src, void *stream)
+{
+    if (mi_blur_device_count() <= 0) return MI_BLUR_ERR_NO_DEVICE;
+    if (!top_src && !bottom_src)
+        return mi_blur_enqueue_band(d_in, d_out, width, band_rows, channels, radius, out_row_begin, out_row_end, stream);
+    LaunchDesc d{};
+    d.in = d_in; d.out = d_out; d.width = width; d.band_rows = band_rows; d.channels = channels;
+    d.radius = radius; d.n_images = 1; d.y0 = out_row_begin; d.y1 = out_row_end;
+    d.variant = MI_BLUR_VARIANT_AUTO; d.stream = (hipStream_t)stream;
+    d.halo_top = top_src; d.halo_bottom = bottom_src;
+    return launch(d);
+}
+
 // Frame layout on the device (replaces the host loops heterogeneous_blur.c:125-134 and split_image_blur.c:40-56).
 extern "C" int mi_blur_planar_to_interleaved(const uint8_t *d_planar, uint8_t *d_interleaved, int width, int height,
                                              int channels, int n_images, void *stream)

@@ -426,6 +426,16 @@ int mi_blur_peer_open(const uint8_t handle[MI_BLUR_PEER_HANDLE_BYTES], uint64_t 
 int mi_blur_peer_close(void *d_ptr, uint64_t offset);
 int mi_blur_halo_pull(uint8_t *d_band, const uint8_t *top_src, const uint8_t *bottom_src, int width, int channels,
                       int owned_rows, int radius, void *stream);
+/* The step as ONE launch: mi_blur_enqueue_band whose kernel reads band rows [0, out_row_begin) from top_src and rows
+ * [out_row_end, band_rows) from bottom_src (each laid out as that many rows, e.g. the same peer addresses mi_blur_halo_pull
+ * takes when out_row_begin = radius) instead of from d_in — the halo rows of d_in are never read or written, the neighbours'
+ * rows cross xGMI inside the blur kernel's own loads.  NULL for a side = that side's rows come from d_in as usual (both NULL =
+ * mi_blur_enqueue_band).  Same rule as the pull: the neighbours must not be writing those rows.  Shapes of the direct kernel
+ * only (1-4 channels, rows a multiple of 16 bytes, 16-byte aligned pointers; MI_BLUR_ERR_UNSUPPORTED otherwise — use
+ * mi_blur_halo_pull + mi_blur_enqueue_band then). */
+int mi_blur_enqueue_band_peer(const uint8_t *d_in, uint8_t *d_out, int width, int band_rows, int channels, int radius,
+                              int out_row_begin, int out_row_end, const uint8_t *top_src, const uint8_t *bottom_src,
+                              void *stream);
 
 /* Single-process form: all n ranks of a mi_blur_comm_init_all set in one RCCL group. */
 int mi_blur_halo_exchange_all(mi_blur_comm **comms, int n, uint8_t **d_bands, int width, int channels,

@@ -371,12 +371,12 @@ def test_bench_spawns_its_own_ranks(pkg):
     assert d["parity"]["status"] == "ok" and d["parity"]["a1_stream"] == dict(d["parity"]["a1_stream"], images_checked_all_ranks=1400, mismatches=0)
     a2 = d["extra"]["a2_8192_rowsplit"]
     assert "configs[4]" in a2["workload"] and a2["rows_per_gpu"] == 4096 and a2["scaling"] == "strong" and a2["img_s"] > 0
-    assert set(a2["step_forms_us"]) == {"plain", "overlapped", "pull"} and a2["quoted_form"] in a2["step_forms_us"] and a2["steps_per_form"] == 200
+    assert set(a2["step_forms_us"]) == {"plain", "overlapped", "pull", "peer"} and a2["quoted_form"] in a2["step_forms_us"] and a2["steps_per_form"] == 200
     assert a2["rccl_ranks"] == 0 and "rehearsal" in a2                    # RCCL exchange leg left out on a one-GPU box, and the line says so
     assert a2["rccl_step_us"] == min(a2["step_forms_us"]["plain"], a2["step_forms_us"]["overlapped"]) and "pulled out of the neighbours" in a2["pull_form"]
     # the pull form is REAL even here (the peer is another process on the same device): it starts from poisoned halo rows
     pa = d["parity"]["a2_8192_rowsplit"]
-    assert pa["ok"] and set(pa["band_fnv"]) == {"plain", "overlapped", "pull"} and set(pa["band_fnv"].values()) == {"0d04249de0140100"}
+    assert pa["ok"] and set(pa["band_fnv"]) == {"plain", "overlapped", "pull", "peer"} and set(pa["band_fnv"].values()) == {"0d04249de0140100"}
     # the configs[3] line survives a configs[4] leg that never completes (a stuck exchange on the first real multi-GPU run):
     # the watchdog fires on every rank, rank 0 prints the line with the error in place of the a2 figures, exit code 0
     r = subprocess.run(cmd + ["--images", "700"], cwd=pkg.ROOT, capture_output=True, text=True, timeout=600,
@@ -432,7 +432,7 @@ def test_bench_a2_two_rank_rehearsal(pkg):
     d = _bench_line(r)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["rows_per_gpu"] == 4096 and d["config"]["halo_bytes_per_neighbour"] == 8192 * 3 and "rehearsal" in d["config"]
-    assert d["config"]["steps_per_form"] == 10 and d["config"]["quoted_form"] in ("plain", "overlapped", "pull") and d["config"]["rccl_ranks"] == 0
+    assert d["config"]["steps_per_form"] == 10 and d["config"]["quoted_form"] in ("plain", "overlapped", "pull", "peer") and d["config"]["rccl_ranks"] == 0
     assert abs(d["ms_per_step"] * 1e3 - min(d["config"]["step_forms_us"].values())) < 0.06      # value quotes the faster form (ms rounded to 1e-4)
     assert d["parity"]["status"] == "ok" and d["parity"]["a2_8192_rowsplit"]["band_fnv"]["plain"] == "0d04249de0140100"
     dec = d["config"]["step_decomposition"]
@@ -535,6 +535,16 @@ def test_resident_row_shards_on_virtual_gpus(apps, O, tmp_path):
             for _ in range(passes):
                 want = O.blur(want, radius)
             assert np.array_equal(read_ppm(tmp_path / fname), want), (ksize, extra, "pull")
+        # the fourth: no exchange at all — every shard's band kernel reads its neighbours' rows in place (one launch per GPU per
+        # step; the shard's own halo rows are poison throughout).  Single blur, and iterated (steps ordered between the GPUs).
+        for extra, fname, passes in (([], "pr_one.ppm", 1), (["--iterate"], "pr_it.ppm", 4)):
+            r = subprocess.run([spl, "--resident", "--transport", "peer", "--gpus", "4", "--size", "320x240", "--ksize", ksize, "--iters", "4",
+                                "--save", fname] + extra, cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
+            assert r.returncode == 0 and "EQUALS the single-device blur" in r.stdout and "read in place by the band kernel" in r.stdout, r.stdout + r.stderr
+            want = src
+            for _ in range(passes):
+                want = O.blur(want, radius)
+            assert np.array_equal(read_ppm(tmp_path / fname), want), (ksize, extra, "peer")
 
 
 @pytest.mark.gpu

@@ -687,6 +687,60 @@ def test_halo_pull_fills_the_halo_rows(pkg, L, O, torch_cuda, radius):
     assert L.mi_blur_halo_pull(t.data_ptr(), None, None, 16, 3, 8, 1, None) == pkg.OK          # no neighbour: nothing to do
 
 
+@pytest.mark.parametrize("radius", [1, 2])
+def test_band_reads_its_halo_rows_from_the_neighbouring_shards(pkg, L, O, torch_cuda, radius):
+    """mi_blur_enqueue_band_peer: the Approach-2 step across GPUs as ONE launch — the band kernel reads the rows above and below
+    its output rows out of the neighbouring shards (peer pointers; other tensors on the same device here) and the shard's own halo
+    rows stay poisoned, untouched.  Shards of one image, every output row == whole-image blur; 1-4 channels, tall and short
+    shards (a shard shorter than one 8-row lane band included), G = 2..5; ineligible shapes are refused, not mis-served."""
+    torch = torch_cuda
+    for (h, w, c, G) in ((96, 320, 3, 3), (64, 64, 1, 2), (40, 128, 4, 5), (33, 48, 2, 4), (1024, 512, 3, 2)):
+        img = O.lcg_image(h, w, c)
+        want = O.blur(img, radius)
+        pitch = w * c
+        bands = [pkg.band_of(h, radius, g, G) for g in range(G)]
+        bufs = []
+        for b in bands:
+            owned = b["row_end"] - b["row_begin"]
+            t = torch.full(((b["halo_top"] + owned + b["halo_bottom"]) * pitch,), 0xA5, dtype=torch.uint8, device="cuda")
+            t[b["halo_top"] * pitch:(b["halo_top"] + owned) * pitch] = torch.from_numpy(img[b["row_begin"]:b["row_end"]].reshape(-1)).cuda()
+            bufs.append(t)
+        got = np.zeros_like(img)
+        for g, b in enumerate(bands):
+            owned = b["row_end"] - b["row_begin"]
+            top_src = bottom_src = None
+            if g > 0:
+                a = bands[g - 1]
+                top_src = bufs[g - 1].data_ptr() + (a["halo_top"] + a["row_end"] - a["row_begin"] - radius) * pitch
+            if g < G - 1:
+                bottom_src = bufs[g + 1].data_ptr() + bands[g + 1]["halo_top"] * pitch
+            rows = b["halo_top"] + owned + b["halo_bottom"]
+            out = torch.zeros(owned * pitch, dtype=torch.uint8, device="cuda")
+            pkg.check(L.mi_blur_enqueue_band_peer(bufs[g].data_ptr(), out.data_ptr(), w, rows, c, radius, b["halo_top"],
+                                                  b["halo_top"] + owned, top_src, bottom_src, None), "enqueue_band_peer")
+            torch.cuda.synchronize()
+            assert "peer halo rows" in L.mi_blur_last_kernel().decode()
+            got[b["row_begin"]:b["row_end"]] = out.cpu().numpy().reshape(owned, w, c)
+            halo = torch.cat([bufs[g][:b["halo_top"] * pitch], bufs[g][(b["halo_top"] + owned) * pitch:]])
+            assert bool((halo == 0xA5).all()), "the shard's own halo rows are neither needed nor written"
+        assert np.array_equal(got, want), (h, w, c, G)
+    # rows that are not whole 16-byte chunks, more than 4 channels: not this kernel's shapes
+    t = torch.zeros(64 * 250 * 3, dtype=torch.uint8, device="cuda")
+    o = torch.zeros_like(t)
+    assert L.mi_blur_enqueue_band_peer(t.data_ptr(), o.data_ptr(), 250, 64, 3, radius, radius, 60, t.data_ptr(), None, None) == pkg.ERR_UNSUPPORTED
+    t = torch.zeros(64 * 64 * 6, dtype=torch.uint8, device="cuda")
+    o = torch.zeros_like(t)
+    assert L.mi_blur_enqueue_band_peer(t.data_ptr(), o.data_ptr(), 64, 64, 6, radius, radius, 60, t.data_ptr(), None, None) == pkg.ERR_UNSUPPORTED
+    assert L.mi_blur_enqueue_band_peer(t.data_ptr(), o.data_ptr(), 64, 64, 4, radius, radius, 60, t.data_ptr() + 4, None, None) == pkg.ERR_INVALID
+    # no neighbour on either side: the plain band launch
+    img = O.lcg_image(32, 64, 3)
+    t = torch.from_numpy(img.reshape(-1)).cuda()
+    o = torch.zeros_like(t)
+    pkg.check(L.mi_blur_enqueue_band_peer(t.data_ptr(), o.data_ptr(), 64, 32, 3, radius, 0, 32, None, None, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(o.cpu().numpy().reshape(32, 64, 3), O.blur(img, radius))
+
+
 def test_resident_pool_placement_trials(pkg, L, O, torch_cuda):
     """mi_blur_resident_alloc places big pools: it times a few candidate placements on the context's kernel and keeps the
     fastest (where a pool lands in HBM moves big launches between two levels ~6 % apart).  The choice is reported; small pools

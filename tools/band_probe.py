@@ -51,6 +51,15 @@ def main():
                     e1.record(); torch.cuda.synchronize()
                     ts.append(e0.elapsed_time(e1) * 1e3 / 100)
                 cells.append(f"pull + band: {sorted(ts)[2]:6.2f} us")
+                ts = []                                # ... and as ONE launch: the band kernel reads the neighbour's rows in place
+                for rep in range(5):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(100):
+                        pkg.check(L.mi_blur_enqueue_band_peer(band.data_ptr(), out.data_ptr(), W, rows, c, radius, ht, ht + owned, src_top, src_bot, stream))
+                    e1.record(); torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1) * 1e3 / 100)
+                cells.append(f"band reading peer rows: {sorted(ts)[2]:6.2f} us")
             print(f"radius {radius}  N={N} band of {owned} rows: " + "   ".join(cells), flush=True)
             del band, out
 
