@@ -249,7 +249,7 @@ int main(int argc, char **argv)
                     mi_blur_shard_range(BATCH_SIZE, g, G, &b, &e);
                     const int nw = (int)std::min<long long>(e - b, 4);
                     if (nw > 0) {
-                        rep.run(gin[g][0], original_image, image_size, nw);
+                        rep.run(gin[g][0], original_image, image_size, nw, true);
                         ok(mi_blur_submit(ctx, gin[g][0], gout[g][0], nw)) && ok(mi_blur_sync(ctx, nullptr));
                         mi_blur_reset_timing(ctx);
                     }
@@ -276,7 +276,7 @@ int main(int argc, char **argv)
                     int done = 0, pieces = 0;
                     while (done < n && feed_rc[g] == MI_BLUR_OK) {     // create batch image stream (:439-442) and hand it over, piece by piece
                         const int m = std::min(feed_piece, n - done);
-                        rep.run(gin[g][s] + (size_t)done * image_size, original_image, image_size, m);
+                        rep.run(gin[g][s] + (size_t)done * image_size, original_image, image_size, m, true);
                         ok(mi_blur_submit(ctx, gin[g][s] + (size_t)done * image_size, gout[g][s] + (size_t)done * image_size, m));
                         done += m; pieces++;
                     }
@@ -371,7 +371,7 @@ int main(int argc, char **argv)
                     first_output.assign(batch_output[s], batch_output[s] + image_size);
             }
             // create batch image stream (contiguous) — heterogeneous_blur.c:439-442
-            replicate.run(batch_input[s], original_image, image_size, batch_count);
+            replicate.run(batch_input[s], original_image, image_size, batch_count, mode == 2);
 
             int num_images_cpu = 0, num_images_gpu = 0;
             mi_blur_a1_partition(mode, batch_count, gpu_ratio, &num_images_cpu, &num_images_gpu);

@@ -29,6 +29,9 @@
 #include <string>
 #include <thread>
 #include <vector>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #ifdef MI_BLUR_WITH_CIMG
 #define cimg_display 0
@@ -258,6 +261,35 @@ inline void report_placement(int g, int ordinal, bool bind)
 // the whole pipeline (6.9 MB per 35-image batch at ~14 GB/s = 0.5 ms against ~0.25 ms of PCIe time), so the
 // hosts spread it over a few persistent helper threads.
 // ------------------------------------------------------------------------------------------------
+// One image into one slot of a batch buffer.  The buffer is written once and next read by the GPU over the host link, never
+// by this core, so the stores bypass the cache (no read-for-ownership of 6.9 MB per batch that the link's own DRAM traffic
+// competes with); glibc's memcpy keeps cached stores for copies this small.  MI_BLUR_HOST_NT_COPY=0 switches back.
+inline bool host_nt_copy()
+{
+    static const bool on = [] { const char *e = getenv("MI_BLUR_HOST_NT_COPY"); return !(e && e[0] == '0'); }();
+    return on;
+}
+inline void copy_to_batch(uint8_t *dst, const uint8_t *src, size_t n)
+{
+#if defined(__SSE2__)
+    if (host_nt_copy() && n >= 4096) {
+        const size_t head = (64 - ((uintptr_t)dst & 63)) & 63;
+        memcpy(dst, src, head); dst += head; src += head; n -= head;
+        const size_t blocks = n / 64;
+        for (size_t i = 0; i < blocks; i++, dst += 64, src += 64) {
+            const __m128i a = _mm_loadu_si128((const __m128i *)src), b = _mm_loadu_si128((const __m128i *)(src + 16));
+            const __m128i c = _mm_loadu_si128((const __m128i *)(src + 32)), d = _mm_loadu_si128((const __m128i *)(src + 48));
+            _mm_stream_si128((__m128i *)dst, a); _mm_stream_si128((__m128i *)(dst + 16), b);
+            _mm_stream_si128((__m128i *)(dst + 32), c); _mm_stream_si128((__m128i *)(dst + 48), d);
+        }
+        memcpy(dst, src, n - blocks * 64);
+        _mm_sfence();
+        return;
+    }
+#endif
+    memcpy(dst, src, n);
+}
+
 class Replicator {
 public:
     // device >= 0: the helper threads keep to the CPUs of that GPU's socket (mi_blur_bind_thread_to_device) — they write
@@ -272,11 +304,14 @@ public:
         cv_.notify_all();
         for (auto &t : workers_) t.join();
     }
-    // dst[i*image_size .. ) = src for i in [0, count)
-    void run(uint8_t *dst, const uint8_t *src, size_t image_size, int count)
+    // dst[i*image_size .. ) = src for i in [0, count).  for_device: the batch is next read by a GPU (not by CPU threads)
+    void run(uint8_t *dst, const uint8_t *src, size_t image_size, int count, bool for_device = false)
     {
-        if (n_ == 1 || count < 2 * n_) { for (int i = 0; i < count; i++) memcpy(dst + (size_t)i * image_size, src, image_size); return; }
-        { std::lock_guard<std::mutex> lk(m_); dst_ = dst; src_ = src; size_ = image_size; count_ = count; pending_ = n_ - 1; gen_++; }
+        if (n_ == 1 || count < 2 * n_) {
+            for (int i = 0; i < count; i++) copy_one(dst + (size_t)i * image_size, src, image_size, for_device);
+            return;
+        }
+        { std::lock_guard<std::mutex> lk(m_); dst_ = dst; src_ = src; size_ = image_size; count_ = count; stream_ = for_device; pending_ = n_ - 1; gen_++; }
         cv_.notify_all();
         part(0);
         std::unique_lock<std::mutex> lk(m_);
@@ -284,10 +319,14 @@ public:
     }
 
 private:
+    static void copy_one(uint8_t *dst, const uint8_t *src, size_t n, bool for_device)
+    {
+        if (for_device) copy_to_batch(dst, src, n); else memcpy(dst, src, n);
+    }
     void part(int w) const
     {
         const int b = (int)((long long)count_ * w / n_), e = (int)((long long)count_ * (w + 1) / n_);
-        for (int i = b; i < e; i++) memcpy(dst_ + (size_t)i * size_, src_, size_);
+        for (int i = b; i < e; i++) copy_one(dst_ + (size_t)i * size_, src_, size_, stream_);
     }
     void loop(int w)
     {
@@ -305,6 +344,7 @@ private:
     unsigned long long gen_ = 0;
     bool stop_ = false;
     uint8_t *dst_ = nullptr; const uint8_t *src_ = nullptr; size_t size_ = 0; int count_ = 0, pending_ = 0;
+    bool stream_ = false;
 };
 
 // ------------------------------------------------------------------------------------------------

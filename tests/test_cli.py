@@ -420,6 +420,26 @@ def test_bench_two_rank_rehearsal_under_launcher(pkg):
 
 
 @pytest.mark.gpu
+def test_bench_a2_four_rank_rehearsal_has_middle_ranks(pkg):
+    """Four ranks on the one GPU: ranks 1 and 2 have a neighbour on BOTH sides — two IPC handles opened, both halo sides pulled
+    / read in place — which no two-rank run exercises.  Every rank's band (2048 rows) in every step form must carry the
+    reference kernel's hash for G = 4; one wrong band on any rank fails the job (status is agreed over all ranks)."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MI_BLUR_BENCH_BACKEND="gloo", MI_BLUR_BENCH_DEVICE="0")
+    r = subprocess.run([sys.executable, os.path.join(pkg.ROOT, "bench.py"), "--workload", "a2", "--gpus", "4", "--steps", "10", "--warmup", "2"],
+                       cwd=pkg.ROOT, env=env, capture_output=True, text=True, timeout=900)
+    d = _bench_line(r)
+    assert d["n_gpus"] == 4 and d["scaling"] == "strong" and d["config"]["rows_per_gpu"] == 2048
+    assert set(d["config"]["step_forms_us"]) == {"plain", "overlapped", "pull", "peer"} and "rehearsal" in d["config"]
+    assert "read" in d["config"]["peer_form"] and "not run" not in d["config"]["pull_form"]
+    golden = json.load(open(os.path.join(pkg.ROOT, "tests", "golden", "blur_golden.json")))["bands8192"]["bands"]["4"]
+    pa = d["parity"]["a2_8192_rowsplit"]
+    assert d["parity"]["status"] == "ok" and pa["ok"] and set(pa["band_fnv"].values()) == {golden[0]}
+
+
+@pytest.mark.gpu
 def test_bench_a2_two_rank_rehearsal(pkg):
     """`bench.py --workload a2 --gpus 2` (BASELINE configs[4] shape of work) spawning its own ranks on a one-GPU box: the
     row split (4096 rows per rank), the timed loop, the per-step decomposition and the overlapped three-launch step all
