@@ -5,7 +5,7 @@ extern "C" int mi_blur_bind_thread_to_device(int) { return 0; }      // the pool
 int main()
 {
     using namespace host;
-    const size_t isz = 3000;
+    const size_t isz = 5003;      // odd, past the 4096-byte threshold of the non-temporal copy: unaligned head and tail on every slot
     std::vector<uint8_t> src(isz), dst(isz * 64);
     for (size_t i = 0; i < isz; i++) src[i] = (uint8_t)(i * 7);
     for (int threads : {1, 2, 5}) {
@@ -13,7 +13,7 @@ int main()
         for (int round = 0; round < 200; round++) {
             const int count = 1 + round % 64;
             memset(dst.data(), 0, dst.size());
-            rep.run(dst.data(), src.data(), isz, count);
+            rep.run(dst.data(), src.data(), isz, count, round % 2 == 1);      // plain memcpy and the streaming-store copy in turn
             for (int i = 0; i < count; i++)
                 if (memcmp(dst.data() + (size_t)i * isz, src.data(), isz)) { printf("REPLICATE MISMATCH\n"); return 1; }
         }
