@@ -135,6 +135,8 @@ struct Tunables {
     int resident_place_trials; // mi_blur_resident_alloc: candidate placements of a big pool that are timed before one is kept (default 4; 0/1 = none)
     int zero_copy_spin;    // waiting for a batch of the server: 0 (default) = spin ~20 us, then sleep in 20 us steps; 1 = spin + yield only
     int zero_copy_trace;   // diagnostics: the batch server's workers stamp their phases per batch (mi_blur_debug_zc_trace)
+    int zero_copy_debug_base; // test hook: a new batch server starts this many batches (and 7x as many tiles) short of 2^32, so that the
+                         // wrap of its batch and tile numbers — 80 minutes into a continuous batch-35 stream — happens at once (0 = off)
     int zero_copy_events; // zero-copy submits: 1 = the dispatch carries start/stop timestamp events (kernel bucket + completion),
                          // 0 = plain launch, completion by stream synchronise (timing experiment: no kernel bucket)
 };

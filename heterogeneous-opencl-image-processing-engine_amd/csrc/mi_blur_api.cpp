@@ -105,6 +105,7 @@ extern "C" int mi_blur_set_option(const char *key, int value)
     else if (!strcmp(key, "zero_copy_trace")) t.zero_copy_trace = value != 0;
     else if (!strcmp(key, "zero_copy_tickets")) t.zero_copy_tickets = value != 0;
     else if (!strcmp(key, "zero_copy_spin")) t.zero_copy_spin = value != 0;
+    else if (!strcmp(key, "zero_copy_debug_base")) { if (value < 0 || value > (1 << 20)) return MI_BLUR_ERR_INVALID; t.zero_copy_debug_base = value; }
     else if (!strcmp(key, "resident_place_trials")) { if (value < 0 || value > 8) return MI_BLUR_ERR_INVALID; t.resident_place_trials = value; }
     else if (!strcmp(key, "zero_copy_workers")) { if (value < 1 || value > 2048) return MI_BLUR_ERR_INVALID; t.zero_copy_workers = value; }
     else if (!strcmp(key, "zero_copy_idle_us")) { if (value < 10 || value > 100000) return MI_BLUR_ERR_INVALID; t.zero_copy_idle_us = value; }
@@ -644,6 +645,18 @@ static int zc_server_submit(mi_blur_ctx *c, Slot &s, const LaunchDesc &d, const 
             const size_t tb = (size_t)ZC_TRACE_BATCHES * (size_t)tun.zero_copy_workers * 5u * sizeof(unsigned long long);
             e = hipMalloc((void **)&z->trace, tb);
             if (e == hipSuccess) e = hipMemsetAsync(z->trace, 0, tb, z->stream);
+        }
+        if (e == hipSuccess && tun.zero_copy_debug_base > 0) {
+            // test hook: start just short of the 2^32 wrap of the batch and tile numbers.  Every word that holds a number is set
+            // to what a server that had really served that many batches would have left behind.
+            const unsigned B = 0u - (unsigned)tun.zero_copy_debug_base, T = 0u - 7u * (unsigned)tun.zero_copy_debug_base;
+            ZcDevCtl init{};
+            init.next[0] = B; init.gnext[0] = T; init.avail = B; init.ticket = T;
+            e = hipMemcpyAsync(z->dev, &init, offsetof(ZcDevCtl, tiles_done), hipMemcpyHostToDevice, z->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(z->stream);      // `init` is on this stack
+            z->ctl->tail = B;
+            for (unsigned i = 0; i < ZC_RING; i++) z->ctl->done[i] = B - ((B - i - 1u) % ZC_RING);   // (last batch before B in slot i) + 1
+            z->head = B; z->tile_base = T;
         }
         if (e == hipSuccess) e = hipStreamSynchronize(z->stream);          // once per context: the fills are done before anything is launched
         if (e != hipSuccess) {

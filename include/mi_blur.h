@@ -103,6 +103,8 @@ const char *mi_blur_last_kernel(void);
  *   "zero_copy_spin"    0 (default) = a wait for a batch of the server spins ~20 us, then sleeps in 20 us steps (the core is
  *                      free for the threads that build the next batch); 1 = spin + yield only
  *   "zero_copy_trace"   0 (default) | 1 = the server's workers stamp their phases (mi_blur_debug_zc_trace)
+ *   "zero_copy_debug_base"  test hook, 0 (default) | n: a context's server starts n batches / 7n tiles short of 2^32, so the
+ *                       wrap of its 32-bit batch and tile numbers (80 minutes into a continuous stream) is reached at once
  *   "zero_copy_events"  1 (default) | 0 = per-batch launches carry no timestamp events (timing experiment; no kernel bucket)
  *   "zero_copy_streams" 4 (default): zero-copy submits of a context alternate over this many of its streams (at most n_slots)
  *   "zero_copy_blocks"  24 (default): zero-copy launches of the aligned tiled kernel keep at most this many workgroups

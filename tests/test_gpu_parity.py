@@ -59,6 +59,7 @@ def reset_opts(L):
     L.mi_blur_set_option(b"zero_copy_workers", 48)
     L.mi_blur_set_option(b"zero_copy_idle_us", 300)
     L.mi_blur_set_option(b"zero_copy_budget", 256)
+    L.mi_blur_set_option(b"zero_copy_debug_base", 0)
     L.mi_blur_set_option(b"resident_place_trials", 4)
 
 
@@ -493,6 +494,59 @@ def test_zero_copy_capped_grid_and_streams(pkg, L, O, torch_cuda, radius):
         pkg.check(L.mi_blur_set_option(b"zero_copy_server", 1))
         pkg.check(L.mi_blur_set_option(b"zero_copy_streams", 4))
         pkg.check(L.mi_blur_set_option(b"zero_copy_blocks", 24))
+        for (pi, po) in bufs:
+            L.mi_blur_host_free(pi); L.mi_blur_host_free(po)
+
+
+@pytest.mark.parametrize("base,budget", [(40, 256), (40, 7), (3, 256), (100, 5)])
+def test_batch_server_number_wrap(pkg, L, O, torch_cuda, base, budget):
+    """The server numbers batches and tiles in 32 bits through the life of a context; a continuous batch-35 stream of 256x256
+    frames uses up the tile numbers in ~80 minutes.  "zero_copy_debug_base" starts a new server `base` batches (7*base tiles)
+    short of 2^32, so both counters wrap inside this test — at different batches, with the server rolling over (budget) before,
+    at and after the wrap, with the descriptor ring coming round across it.  Every batch is verified and its output poisoned
+    again before its buffers are reused."""
+    h, w, c, n, radius = 96, 320, 3, 9, 1
+    nbuf = 4
+    host = O.lcg_stream(nbuf * n, h, w, c, first_index=900)
+    want = O.blur_batch(host, radius)
+    nbytes = n * h * w * c
+    bufs = [(L.mi_blur_host_alloc(nbytes), L.mi_blur_host_alloc(nbytes)) for _ in range(nbuf)]
+    as_np = lambda ptr, m=n: np.ctypeslib.as_array((C.c_uint8 * (m * h * w * c)).from_address(ptr)).reshape(m, h, w, c)
+    pkg.check(L.mi_blur_set_option(b"zero_copy_debug_base", base))
+    pkg.check(L.mi_blur_set_option(b"zero_copy_budget", budget))
+    pkg.check(L.mi_blur_set_option(b"zero_copy_trace", 1))        # only for the server's own batch count below
+    try:
+        for k, (pi, po) in enumerate(bufs):
+            C.memmove(pi, host[k * n:(k + 1) * n].ctypes.data, nbytes)
+            C.memset(po, 0xEE, nbytes)
+        rng = np.random.default_rng(base * 31 + budget)
+        with pkg.Context(0, w, h, c, radius, max_batch=n, n_slots=nbuf) as ctx:
+            sizes = [n] * nbuf
+            total = 3 * base + 150
+            for i in range(total):
+                k = i % nbuf
+                if i >= nbuf:
+                    ctx.wait_oldest()
+                    assert np.array_equal(as_np(bufs[k][1])[:sizes[k]], want[k * n:k * n + sizes[k]]), i
+                    assert bool((as_np(bufs[k][1])[sizes[k]:] == 0xEE).all()), i
+                    C.memset(bufs[k][1], 0xEE, nbytes)
+                sizes[k] = int(rng.integers(1, n + 1))
+                if i % 29 == 28:
+                    time.sleep(0.001)                                          # idle time-out: a fresh server picks up across the wrap too
+                ctx.submit(bufs[k][0], bufs[k][1], sizes[k])
+            ctx.sync()
+            for k in range(nbuf):
+                assert np.array_equal(as_np(bufs[k][1])[:sizes[k]], want[k * n:k * n + sizes[k]]), k
+            assert L.mi_blur_zero_copy_launches(ctx.h) == total and L.mi_blur_last_kernel() == b"blur_server_kernel"
+            # the server's own batch number has gone through 2^32: it started at 2^32 - base and stands at total - base now
+            nw, head = C.c_int(), C.c_uint()
+            tr = np.zeros(48 * 5, np.uint64)
+            pkg.check(min(0, L.mi_blur_debug_zc_trace(ctx.h, tr.ctypes.data_as(C.POINTER(C.c_uint64)), 1, C.byref(nw), C.byref(head))))
+            assert head.value == total - base
+    finally:
+        pkg.check(L.mi_blur_set_option(b"zero_copy_trace", 0))
+        pkg.check(L.mi_blur_set_option(b"zero_copy_debug_base", 0))
+        pkg.check(L.mi_blur_set_option(b"zero_copy_budget", 256))
         for (pi, po) in bufs:
             L.mi_blur_host_free(pi); L.mi_blur_host_free(po)
 
