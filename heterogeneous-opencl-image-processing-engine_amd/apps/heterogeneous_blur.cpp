@@ -127,7 +127,10 @@ int main(int argc, char **argv)
     // GPU-only mode from host buffers: 4 rotating buffer sets, so up to 4 zero-copy launches (each capped to a few dozen
     // workgroups, library default) overlap and keep both directions of the host link busy: 173-180 k img/s at batch 35
     // against 141-146 k with 2 sets (profiles/r02_e2e.txt).  With CPU threads in the loop (both) 2 sets stay best.
-    const int nslots = opt.slots_given ? opt.slots : ((opt.resident || mode == 2) ? 4 : opt.slots);
+    // buffer sets in flight: 4 wherever a GPU takes part (with the batch server a deeper queue costs the link nothing and keeps
+    // the GPU fed while the host builds / the CPU device works: `both` 35 runs 25-40 % faster on 4 sets than on 2,
+    // profiles/r03_hosts_e2e.txt), the reference's 2 for the CPU device alone
+    const int nslots = opt.slots_given ? opt.slots : (mode != 1 ? 4 : opt.slots);
     const int resident_timed_every = 16;
     Dev cpu;
     std::vector<Dev> gpus(G);

@@ -163,8 +163,8 @@ struct Options {
     bool images_given = false;
     int gpus = 1;                        // --gpus G
     bool slots_given = false;
-    int slots = 2;                       // --slots S    staging slots / batch buffers in flight (2 measured best:
-                                         // more concurrent H2D+D2H only contend on the host link)
+    int slots = 2;                       // --slots S    batch buffer sets in flight.  Not given: 4 where a GPU takes part in
+                                         // heterogeneous_blur, 3 in split_image_blur, 2 for the CPU device alone
     int threads = 0;                     // --threads T  CPU device threads (0 = all cores)
     int host_threads = 4;                // --host-threads T  helper threads that build each batch's stream
     bool verbose = false;                // --verbose    per-batch progress lines (heterogeneous_blur.c:420,463,599)
