@@ -530,6 +530,10 @@ struct FusedParams {
     unsigned tiles_per_batch; // batch_images * tiles per image
     int release;              // 1 = release-ordered completion add (agent scope): the architectural form, ~6x slower
     unsigned window;          // batches per window of the blockIdx -> tile map (>= 1)
+    // dynamic tail (blur_fused_tail_kernel): the pass's last `ntail` tiles are not mapped to blocks; `nextra` extra blocks at the
+    // end of the grid draw them from *tail_ctr one by one and leave when none is left
+    unsigned *tail_ctr;
+    unsigned nstatic, ntail, nextra;
 };
 
 template <int C, int R, int RPG>
@@ -551,6 +555,47 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(const TiledParams p, co
     // every block does one), no returning atomic (its round trip would keep the block's LDS allocated).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                       // every wave of the block has drained (one atomic per block: the counters are hot spots)
+    if (threadIdx.x == 0) {
+        if (f.release) __hip_atomic_fetch_add(&f.count[b * 8u + ((w ^ (w >> 3)) & 7u)], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_fetch_add(&f.count[b * 8u + ((w ^ (w >> 3)) & 7u)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// The fused stream with a DYNAMIC TAIL.  The hardware deals workgroups to the eight XCDs in strict rotation, so with one tile per
+// workgroup every XCD blurs exactly an eighth of the pass, and the pass ends when the slowest XCD does (3-5 % after the fastest,
+// profiles/r02_xcd_finish_times.txt).  Here the last `ntail` tiles of the pass belong to no block: the grid ends in `nextra`
+// (> ntail) extra blocks, which every XCD reaches when it is through its share; each draws a ticket and blurs that tail tile, or
+// leaves if the tail is gone.  An XCD that runs ahead so takes more of the tail, one that lags takes less.  Every extra
+// block draws exactly once, so the one that draws ticket nextra-1 knows it is the last and resets the counter for the next pass.
+template <int C, int R, int RPG>
+__global__ __launch_bounds__(256) void blur_fused_tail_kernel(const TiledParams p, const FusedParams f)
+{
+    // (one call site of the tile code, reached by both kinds of block: with the tile code inside a ticket loop the same
+    // compiler schedules the whole kernel 2.6x slower)
+    unsigned tile, w;
+    if (blockIdx.x >= f.nstatic) {
+        __shared__ unsigned s_ticket;
+        if (threadIdx.x == 0) {
+            const unsigned t = __hip_atomic_fetch_add(f.tail_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == f.nextra - 1u) __hip_atomic_store(f.tail_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_ticket = t;
+        }
+        __syncthreads();
+        const unsigned t = __builtin_amdgcn_readfirstlane(s_ticket);
+        if (t >= f.ntail) return;
+        tile = f.nstatic + t;
+        w = t;
+    } else {
+        const unsigned tpw = f.tiles_per_batch * f.window;
+        const unsigned wnd = blockIdx.x / tpw, base = wnd * tpw;
+        const unsigned nw = min(tpw, f.nstatic - base);
+        w = blockIdx.x - base;
+        tile = base + (nw >= 16 ? xcd_map(w, nw, p.xcd) : w);
+    }
+    const unsigned b = tile / f.tiles_per_batch;
+    tiled_tile<C, R, RPG, true, false, false, true>(p, tile);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (threadIdx.x == 0) {
         if (f.release) __hip_atomic_fetch_add(&f.count[b * 8u + ((w ^ (w >> 3)) & 7u)], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         else __hip_atomic_fetch_add(&f.count[b * 8u + ((w ^ (w >> 3)) & 7u)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1123,8 +1168,10 @@ static Tunables &tunables_storage()
         v.zero_copy_streams = 4; v.zero_copy_blocks = 24; v.stream_updown = 1; v.prefer_direct = 1; v.direct_bh = 8; v.fused_window = 8;
         v.zero_copy_server = 1; v.zero_copy_workers = 48; v.zero_copy_idle_us = 300; v.zero_copy_budget = 256; v.zero_copy_tickets = 1;
         v.zero_copy_events = 1;
+        v.fused_tail = 30; v.fused_tail_blocks = 25;
         v.resident_place_trials = 4;
         if (const char *e = getenv("MI_BLUR_PLACE_TRIALS")) { const int r = atoi(e); if (r >= 0 && r <= 8) v.resident_place_trials = r; }
+        if (const char *e = getenv("MI_BLUR_FUSED_TAIL")) { const int r = atoi(e); if (r >= 0 && r <= 500) v.fused_tail = r; }
         if (const char *e = getenv("MI_BLUR_STAGE")) v.stage_dma = strcmp(e, "reg") != 0;
         if (const char *e = getenv("MI_BLUR_RPG")) { const int r = atoi(e); v.rpg = (r == 4 || r == 8 || r == 16) ? r : 0; }
         if (const char *e = getenv("MI_BLUR_XCD")) v.xcd_remap = atoi(e) != 0;
@@ -1269,6 +1316,19 @@ static int launch_fused_r(const LaunchDesc &d, const TiledParams &p, const Fused
         else hipLaunchKernelGGL(kernel, grid, block, lds, d.stream, p, f);
         return hip_status(hipGetLastError());
     };
+    if (f.tail_ctr) {
+        switch (d.channels * 10 + rpg) {
+        case 14: return go(blur_fused_tail_kernel<1, R, 4>);
+        case 18: return go(blur_fused_tail_kernel<1, R, 8>);
+        case 24: return go(blur_fused_tail_kernel<2, R, 4>);
+        case 28: return go(blur_fused_tail_kernel<2, R, 8>);
+        case 34: return go(blur_fused_tail_kernel<3, R, 4>);
+        case 38: return go(blur_fused_tail_kernel<3, R, 8>);
+        case 44: return go(blur_fused_tail_kernel<4, R, 4>);
+        case 48: return go(blur_fused_tail_kernel<4, R, 8>);
+        }
+        return MI_BLUR_ERR_INVALID;
+    }
     switch (d.channels * 10 + rpg) {
     case 14: return go(blur_fused_kernel<1, R, 4>);
     case 18: return go(blur_fused_kernel<1, R, 8>);
@@ -1368,6 +1428,18 @@ static int launch_tiled(const LaunchDesc &d, const Tunables &tun, bool ragged = 
         if (fused->total_blocks) *fused->total_blocks = (unsigned)nblocks;
         if (fused->geometry_only) return MI_BLUR_OK;
         p.debug_copy = 0;
+        // dynamic tail ("fused_tail" t, per mille of the pass's tiles; 0 = off): worth it only when the pass is many rounds of
+        // resident workgroups long; the counter comes from a small ring so that passes in flight on different streams do not share one
+        if (tun.fused_tail > 0 && fused->tail_ctr && nblocks >= 8192) {
+            const unsigned ntail = (unsigned)(nblocks * tun.fused_tail / 1000);
+            if (ntail >= 8) {
+                f.tail_ctr = fused->tail_ctr; f.ntail = ntail; f.nstatic = (unsigned)nblocks - ntail;
+                f.nextra = ntail + (unsigned)((long long)ntail * std::max(10, tun.fused_tail_blocks) / 100);
+                g_last_kernel = "blur_fused_tail_kernel";
+                const dim3 tgrid(f.nstatic + f.nextra);
+                return R == 1 ? launch_fused_r<1>(d, p, f, tgrid, block, lds, rpg) : launch_fused_r<2>(d, p, f, tgrid, block, lds, rpg);
+            }
+        }
         return R == 1 ? launch_fused_r<1>(d, p, f, grid, block, lds, rpg) : launch_fused_r<2>(d, p, f, grid, block, lds, rpg);
     }
     return R == 1 ? launch_tiled_r<1>(d, p, grid, block, lds, rpg, tun.stage_dma != 0, ragged, tun.row_shuffle != 0, tun.experiment)

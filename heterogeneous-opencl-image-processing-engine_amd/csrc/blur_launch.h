@@ -39,6 +39,7 @@ struct Tunables;
 struct FusedDesc {
     unsigned *count; int batch_images; unsigned *tiles_per_batch, *waves_per_block, *total_blocks;
     const Tunables *tun; bool geometry_only;
+    unsigned *tail_ctr;     // device word, zero between passes: ticket counter of the pass's dynamic tail ("fused_tail"); nullptr = none
 };
 int launch_fused(const LaunchDesc &d, const FusedDesc &f);
 // Watcher of one fused pass (fused_watch_kernel, one wave on a stream of its own): follows the per-batch counters and keeps
@@ -126,6 +127,8 @@ struct Tunables {
     int direct_bh;       // direct variant: output rows per lane (8; 4 | 12 | 16 instantiated for C = 3 only, A/B runs)
     int debug_xcd_times; // diagnostics: the tiled kernel's workgroups leave start/end times per XCD (mi_blur_debug_xcd_times)
     int fused_window;    // fused stream: batches per window of its blockIdx -> tile map (8: one whole batch per XCD per window)
+    int fused_tail;      // fused stream: per mille of a pass's tiles that are handed out dynamically at the end (0 = none)
+    int fused_tail_blocks; // ... by (100 + this) % as many extra workgroups as there are tail tiles (one ticket each; default 100)
     int zero_copy_server;  // zero-copy submits of aligned shapes go through the batch server (one long-lived dispatch per stream of
                            // batches, blur_server_kernel) instead of one launch per batch: 1 (default) | 0
     int zero_copy_workers; // batch server: worker workgroups (default 48: 40-64 measured best, profiles/r03_e2e_timeline.md)

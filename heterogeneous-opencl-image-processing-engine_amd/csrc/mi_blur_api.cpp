@@ -98,6 +98,8 @@ extern "C" int mi_blur_set_option(const char *key, int value)
     else if (!strcmp(key, "zero_copy_blocks")) { if (value < 0 || value > (1 << 20)) return MI_BLUR_ERR_INVALID; t.zero_copy_blocks = value; }
     else if (!strcmp(key, "prefer_direct")) { if (value < 0 || value > 2) return MI_BLUR_ERR_INVALID; t.prefer_direct = value; }
     else if (!strcmp(key, "direct_bh")) { if (value != 4 && value != 8 && value != 12 && value != 16) return MI_BLUR_ERR_INVALID; t.direct_bh = value; }
+    else if (!strcmp(key, "fused_tail_blocks")) { if (value < 10 || value > 800) return MI_BLUR_ERR_INVALID; t.fused_tail_blocks = value; }
+    else if (!strcmp(key, "fused_tail")) { if (value < 0 || value > 500) return MI_BLUR_ERR_INVALID; t.fused_tail = value; }
     else if (!strcmp(key, "fused_window")) { if (value < 1 || value > 4096) return MI_BLUR_ERR_INVALID; t.fused_window = value; }
     else if (!strcmp(key, "debug_xcd_times")) t.debug_xcd_times = value != 0;
     else if (!strcmp(key, "zero_copy_events")) t.zero_copy_events = value != 0;
@@ -558,6 +560,8 @@ extern "C" int mi_blur_sync(mi_blur_ctx *c, mi_blur_timing *timing)
             if (rc) return rc;
         }
         for (auto &s : c->slots) HIP_TRY(hipStreamSynchronize(s.stream));
+        // a watched fused pass: its watcher (own stream) ends with the pass; after a sync the count it published is final
+        if (c->fused_watched && c->fused_watch) HIP_TRY(hipStreamSynchronize(c->fused_watch));
         harvest_resident(c);
         c->zc_ref_valid = false;                                 // everything drained: the next zero-copy launch starts a new window
     }
@@ -1161,7 +1165,10 @@ extern "C" int mi_blur_resident_run_fused(mi_blur_ctx *c, int n_images, int batc
         if (c->fused_host) { (void)hipHostFree(c->fused_host); c->fused_host = nullptr; }
         c->fused_cap = 0;
         const int cap = std::max(nb, c->pool_images);      // enough for any batch size on this pool: never reallocated
-        HIP_TRY(hipMalloc((void **)&c->fused_count, sizeof(unsigned) * 8 * (size_t)cap));
+        // (+16 words: the ticket counter of a pass's dynamic tail lives behind the batch counters; it is zero between passes)
+        HIP_TRY(hipMalloc((void **)&c->fused_count, sizeof(unsigned) * (8 * (size_t)cap + 16)));
+        HIP_TRY(hipMemset(c->fused_count + 8 * (size_t)cap, 0, sizeof(unsigned) * 16));
+        HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipHostMalloc((void **)&c->fused_host, sizeof(unsigned) * 8 * (size_t)cap, hipHostMallocDefault));
         c->fused_cap = cap;
         c->fused_passes = 0;
@@ -1184,7 +1191,7 @@ extern "C" int mi_blur_resident_run_fused(mi_blur_ctx *c, int n_images, int batc
     // knobs, ask for the geometry first, launch with the same copy.
     const Tunables tun = tunables();
     unsigned tpb = 0, wpb = 0, blocks = 0;
-    FusedDesc f{c->fused_count, batch, &tpb, &wpb, &blocks, &tun, true};
+    FusedDesc f{c->fused_count, batch, &tpb, &wpb, &blocks, &tun, true, c->fused_count + 8 * (size_t)c->fused_cap};
     int rc = launch_fused(d, f);
     if (rc) return rc;
     // Repeated passes of the same shape AND geometry do not zero the counters (that would be one more dispatch per

@@ -471,7 +471,7 @@ def test_bench_default_line_carries_every_single_gpu_config(pkg):
                        capture_output=True, text=True, timeout=900)
     d = _bench_line(r)
     assert d["n_gpus"] == 1 and d["dtype"] == "u8" and "configs[1]" in d["config"]["workload"] and d["vs_baseline"] is None
-    assert 0 < d["roofline"]["frac"] <= 1 and d["roofline"]["kernel"] == "blur_fused_kernel" and d["roofline"]["launches_timed"] == 20
+    assert 0 < d["roofline"]["frac"] <= 1 and d["roofline"]["kernel"] == "blur_fused_tail_kernel" and d["roofline"]["launches_timed"] == 20
     cb = d["cpu_baseline"]
     assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port"
     assert cb["one_thread"]["cores"] == 1 and 0 < cb["one_thread"]["value"] <= cb["value"] * 1.05

@@ -60,6 +60,8 @@ def reset_opts(L):
     L.mi_blur_set_option(b"zero_copy_idle_us", 300)
     L.mi_blur_set_option(b"zero_copy_budget", 256)
     L.mi_blur_set_option(b"zero_copy_debug_base", 0)
+    L.mi_blur_set_option(b"fused_tail", 30)
+    L.mi_blur_set_option(b"fused_tail_blocks", 25)
     L.mi_blur_set_option(b"resident_place_trials", 4)
 
 
@@ -1269,6 +1271,45 @@ def test_fused_stream_parity_and_batch_flags(pkg, L, O, torch_cuda):
     with pkg.Context(0, 17, 9, 3, 1, max_batch=1, n_slots=1) as ctx:
         ctx.resident_alloc(4)
         assert L.mi_blur_resident_run_fused(ctx.h, 4, 2, 0) == pkg.ERR_UNSUPPORTED
+
+
+def test_fused_stream_dynamic_tail(pkg, L, O, torch_cuda):
+    """Big fused passes hand their last tiles out dynamically (blur_fused_tail_kernel: extra workgroups at the end of the grid
+    draw tickets, so an XCD that runs ahead takes more of the tail).  Every image equals the oracle, every batch is counted
+    exactly once per pass — over repeated passes (the ticket counter resets itself), tails of 3 % / 20 % / 50 % of the pass, few
+    and many spare workgroups, the release-ordered count, a watched pass; passes below 8192 tiles keep the static kernel."""
+    for (h, w, c, r, n, batch) in [(64, 64, 3, 1, 9000, 35), (32, 48, 4, 2, 8200, 100)]:
+        src = O.lcg_stream(n, h, w, c, first_index=11)
+        want = O.blur_batch(src, r)
+        nb = (n + batch - 1) // batch
+        for tail, spare, release in ((30, 25, 0), (200, 10, 0), (500, 100, 0), (30, 25, 1), (0, 25, 0)):
+            pkg.check(L.mi_blur_set_option(b"fused_tail", tail))
+            pkg.check(L.mi_blur_set_option(b"fused_tail_blocks", spare))
+            pkg.check(L.mi_blur_set_option(b"fused_release", release))
+            try:
+                with pkg.Context(0, w, h, c, r, max_batch=1, n_slots=1) as ctx:
+                    ctx.resident_alloc(n)
+                    ctx.resident_fill_synthetic(11)
+                    for rep in range(3):
+                        ctx.resident_run_fused(n, batch, watch=(rep == 2))
+                        assert L.mi_blur_last_kernel() == (b"blur_fused_tail_kernel" if tail else b"blur_fused_kernel")
+                        ctx.sync()
+                        assert ctx.resident_batches_done() == nb, (h, w, tail, spare, rep)
+                        out = np.zeros_like(src)
+                        ctx.resident_download(0, out.ctypes.data, n)
+                        assert np.array_equal(out, want), (h, w, c, r, tail, spare, release, rep)
+                    # a shorter pass on the same context (another geometry, below the threshold: static kernel) and back
+                    ctx.resident_run_fused(1000, batch)
+                    assert L.mi_blur_last_kernel() == b"blur_fused_kernel"
+                    ctx.sync()
+                    assert ctx.resident_batches_done() == (1000 + batch - 1) // batch
+                    ctx.resident_run_fused(n, batch)
+                    ctx.sync()
+                    assert ctx.resident_batches_done() == nb
+            finally:
+                pkg.check(L.mi_blur_set_option(b"fused_tail", 30))
+                pkg.check(L.mi_blur_set_option(b"fused_tail_blocks", 25))
+                pkg.check(L.mi_blur_set_option(b"fused_release", 0))
 
 
 def test_fused_stream_random_shapes(pkg, L, O, torch_cuda):

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--burst", type=int, default=1,
                     help="launches issued back to back per measurement (1 = isolated launches; 100+ = the sustained regime "
                          "bench.py measures, where the clock settles under load)")
+    ap.add_argument("--fused", action="store_true", help="the pass as ONE fused dispatch (mi_blur_resident_run_fused) instead of one launch per batch")
     ap.add_argument("--opts", default="stage_dma=0,1;rows_per_thread=8,16;xcd_remap=1")
     args = ap.parse_args()
     import torch  # noqa: F401  (before the library: one HIP runtime)
@@ -58,7 +59,10 @@ def main():
                     pkg.check(L.mi_blur_set_option(k.encode(), v))
                 ctx.reset_timing()
                 for _ in range(args.burst):
-                    ctx.resident_run(per_pass, batch, timed=True)
+                    if args.fused:
+                        ctx.resident_run_fused(per_pass, batch, timed=True)
+                    else:
+                        ctx.resident_run(per_pass, batch, timed=True)
                 tm = ctx.sync()
                 if rep:
                     res[cb].append((tm["kernel_ms"] * 1e3 / tm["launches"], tm["bytes_alg"] / tm["launches"]))
