@@ -1200,6 +1200,9 @@ extern "C" int mi_blur_resident_run_fused(mi_blur_ctx *c, int n_images, int batc
         blocks == c->fused_blocks && c->fused_passes > 0 && c->fused_passes < (1u << 20)) {
         c->fused_passes += 1;
     } else {
+        // the counters are about to be zeroed: a watcher of the previous pass must have seen that pass's last counts first
+        // (it ends with its pass; zeros under it would leave it waiting for its hard limit)
+        if (c->fused_watched && c->fused_watch) HIP_TRY(hipStreamSynchronize(c->fused_watch));
         HIP_TRY(hipMemsetAsync(c->fused_count, 0, sizeof(unsigned) * 8 * (size_t)nb, s.stream));
         c->fused_n = n_images; c->fused_batch = batch; c->fused_passes = 1;
         c->fused_tpb = tpb; c->fused_wpb = wpb; c->fused_blocks = blocks;

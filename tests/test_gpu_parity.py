@@ -1306,6 +1306,16 @@ def test_fused_stream_dynamic_tail(pkg, L, O, torch_cuda):
                     ctx.resident_run_fused(n, batch)
                     ctx.sync()
                     assert ctx.resident_batches_done() == nb
+                    # a WATCHED pass with passes queued straight behind it — the same geometry (the counters count on under the
+                    # watcher) and another one (the counters are zeroed): the watcher ends with its own pass either way
+                    t0 = time.perf_counter()
+                    ctx.resident_run_fused(n, batch, watch=True)
+                    ctx.resident_run_fused(n, batch)
+                    ctx.resident_run_fused(n, batch, watch=True)
+                    ctx.resident_run_fused(n // 2, batch + 1)
+                    ctx.sync()
+                    assert time.perf_counter() - t0 < 5.0, "a watcher outlived its pass (it would sit out its 10 s hard limit)"
+                    assert ctx.resident_batches_done() == (n // 2 + batch) // (batch + 1)
             finally:
                 pkg.check(L.mi_blur_set_option(b"fused_tail", 30))
                 pkg.check(L.mi_blur_set_option(b"fused_tail_blocks", 25))
