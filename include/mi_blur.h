@@ -115,6 +115,10 @@ const char *mi_blur_last_kernel(void);
  *   "fused_window"     8 (default): the fused stream takes its tiles window by window, a window being this many consecutive
  *                      batches dealt over the XCDs (8 = one whole batch per XCD); the batches of a window complete at about
  *                      the same time, windows in stream order.  1 = batch by batch
+ *   "fused_tail"       30 (default; MI_BLUR_FUSED_TAIL in the environment): per mille of a fused pass's tiles that are handed out
+ *                      by ticket to spare workgroups at the end of the grid instead of being mapped to workgroups, so that an
+ *                      XCD that runs ahead takes more of them (passes of >= 8192 tiles; -1.3..1.8 % per pass).  0 = static map
+ *   "fused_tail_blocks" 25 (default): spare workgroups beyond the number of tail tiles, per cent
  *   "fused_release"    0 (default) | 1: how a block of the fused stream publishes "my outputs are in memory" — see
  *                      mi_blur_resident_run_fused */
 int mi_blur_set_option(const char *key, int value);
@@ -169,9 +173,10 @@ typedef struct mi_blur_timing {      /* cumulative since create / last reset; mi
 } mi_blur_timing;
 
 /* device: HIP ordinal, or MI_BLUR_DEVICE_CPU (n_threads host threads; 0 = all cores, at most 16 — ask for more by number).
- * max_batch: largest n_images of one submit.  n_slots: staging slots (>=1; 2-3 lets
- * H2D(n+1), kernel(n) and D2H(n-1) overlap).  Each slot owns a pinned in/out pair,
- * a device in/out pair and one stream. */
+ * max_batch: largest n_images of one submit.  n_slots: submits in flight (>=1).  Staged submits: 2-3 lets H2D(n+1),
+ * kernel(n) and D2H(n-1) overlap.  In-place (pinned) submits through the batch server: a deeper queue costs the link
+ * nothing and keeps the GPU fed while the host builds the next batch — the hosts use 4 (3 in split_image_blur).  Each
+ * slot owns a pinned in/out pair, a device in/out pair and one stream. */
 int mi_blur_create(mi_blur_ctx **out_ctx, int device, int width, int height, int channels,
                    int radius, int max_batch, int n_slots, int n_threads);
 void mi_blur_destroy(mi_blur_ctx *ctx);
