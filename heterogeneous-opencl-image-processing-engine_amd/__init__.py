@@ -334,3 +334,34 @@ class Context:
         n, b = C.c_uint64(), C.c_uint64()
         lib().mi_blur_timed_coverage(self.h, C.byref(n), C.byref(b))
         return n.value, b.value
+
+
+def blur(images, ksize: int = 3, device: int = 0, batch: int = 0):
+    """Convenience for Python callers: the reference's blur of a stack of interleaved uint8 images, numpy in -> numpy out.
+
+    images: (H, W), (H, W, C) or (N, H, W, C) uint8.  ksize 3 (the reference kernel, gaussian_kernel.cl:36-41) or
+    5.  device: HIP ordinal, or DEVICE_CPU for the host-thread device.  batch: images per submit (0 = all at once, at most 4096).
+    Goes through mi_blur_create / mi_blur_submit / mi_blur_sync like any host; there is no other code path behind it."""
+    import numpy as np
+    a = np.ascontiguousarray(images)
+    if a.dtype != np.uint8 or a.ndim not in (2, 3, 4):
+        raise ValueError("blur: a uint8 array of shape (H, W), (H, W, C) or (N, H, W, C)")
+    if ksize not in (3, 5):
+        raise ValueError("blur: ksize 3 or 5")
+    single = a.ndim in (2, 3)
+    if a.ndim == 2:
+        a = a[None, :, :, None]
+    elif a.ndim == 3:
+        a = a[None]
+    n, h, w, c = a.shape
+    out = np.empty_like(a)
+    if n == 0 or a.size == 0:
+        return out[0] if single else out
+    per = min(n, batch if batch > 0 else 4096)
+    isz = h * w * c
+    with Context(device, w, h, c, (ksize - 1) // 2, max_batch=per, n_slots=2) as ctx:
+        for i in range(0, n, per):
+            m = min(per, n - i)
+            ctx.submit(a.ctypes.data + i * isz, out.ctypes.data + i * isz, m)
+        ctx.sync()
+    return out[0] if single else out

@@ -180,6 +180,26 @@ def test_cpu_context_submit_and_band(pkg, L, O):
         assert np.array_equal(np.concatenate([top, bot]), whole)
 
 
+def test_numpy_convenience_on_the_cpu_device(pkg, O):
+    """pkg.blur(): numpy in -> numpy out through create / submit / sync (here on the host-thread device; the GPU form is in
+    tests/test_gpu_parity.py): single image, stack, grey image, 3x3 and 5x5, submits in several batches, bad arguments."""
+    import numpy as np
+    stack = O.lcg_stream(7, 33, 40, 3, first_index=2)
+    for ksize in (3, 5):
+        want = O.blur_batch(stack, (ksize - 1) // 2)
+        assert np.array_equal(pkg.blur(stack, ksize, device=pkg.DEVICE_CPU), want)
+        assert np.array_equal(pkg.blur(stack, ksize, device=pkg.DEVICE_CPU, batch=3), want)
+        assert np.array_equal(pkg.blur(stack[4], ksize, device=pkg.DEVICE_CPU), want[4])
+        grey = np.ascontiguousarray(stack[1][:, :, 0])
+        assert np.array_equal(pkg.blur(grey, ksize, device=pkg.DEVICE_CPU)[:, :, 0], O.blur(grey[:, :, None], (ksize - 1) // 2)[:, :, 0])
+    assert pkg.blur(np.zeros((0, 8, 8, 3), np.uint8), device=pkg.DEVICE_CPU).shape == (0, 8, 8, 3)
+    for bad in (stack.astype(np.float32), np.zeros(5, np.uint8)):
+        with pytest.raises(ValueError):
+            pkg.blur(bad, device=pkg.DEVICE_CPU)
+    with pytest.raises(ValueError):
+        pkg.blur(stack, 7, device=pkg.DEVICE_CPU)
+
+
 def test_synthetic_stream_matches_oracle_generator(pkg, L, O):
     a = np.empty((5, 8, 12, 3), np.uint8)
     L.mi_blur_fill_synthetic(a.ctypes.data, 12, 8, 3, 40, 5, 3)

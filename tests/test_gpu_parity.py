@@ -703,6 +703,18 @@ def test_zero_copy_batch_server(pkg, L, O, torch_cuda, radius):
             L.mi_blur_host_free(pi); L.mi_blur_host_free(po)
 
 
+def test_numpy_convenience(pkg, O, torch_cuda):
+    """pkg.blur() on the GPU: pageable numpy arrays through the staged submit path, one submit and several."""
+    stack = O.lcg_stream(40, 96, 128, 3, first_index=5)
+    for ksize in (3, 5):
+        want = O.blur_batch(stack, (ksize - 1) // 2)
+        assert np.array_equal(pkg.blur(stack, ksize), want)
+        assert np.array_equal(pkg.blur(stack, ksize, batch=16), want)
+        assert np.array_equal(pkg.blur(stack[9], ksize), want[9])
+    odd = O.lcg_stream(3, 31, 50, 3)                       # rows of 150 bytes: not the tiled kernel's shape
+    assert np.array_equal(pkg.blur(odd), O.blur_batch(odd, 1))
+
+
 @pytest.mark.parametrize("radius", [1, 2])
 def test_halo_pull_fills_the_halo_rows(pkg, L, O, torch_cuda, radius):
     """mi_blur_halo_pull: a rank's halo rows copied straight out of its neighbours' shards by one small kernel (here the
