@@ -131,6 +131,8 @@ struct Tunables {
     int fused_tail_blocks; // ... by (100 + this) % as many extra workgroups as there are tail tiles (one ticket each; default 100)
     int zero_copy_server;  // zero-copy submits of aligned shapes go through the batch server (one long-lived dispatch per stream of
                            // batches, blur_server_kernel) instead of one launch per batch: 1 (default) | 0
+    int staged_server;     // submits of PAGEABLE caller memory: 1 (default) = the batch server works on the slot's pinned staging buffers in
+                           // place, 0 = DMA copy in, launch on device buffers, DMA copy out
     int zero_copy_workers; // batch server: worker workgroups (default 48: 40-64 measured best, profiles/r03_e2e_timeline.md)
     int zero_copy_idle_us; // batch server: leaves after this long without a new batch (default 300)
     int zero_copy_budget;  // batch server: leaves after this many batches, the queued next one carries on (default 256)

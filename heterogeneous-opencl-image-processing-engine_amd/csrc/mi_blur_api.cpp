@@ -104,6 +104,7 @@ extern "C" int mi_blur_set_option(const char *key, int value)
     else if (!strcmp(key, "debug_xcd_times")) t.debug_xcd_times = value != 0;
     else if (!strcmp(key, "zero_copy_events")) t.zero_copy_events = value != 0;
     else if (!strcmp(key, "zero_copy_server")) t.zero_copy_server = value != 0;
+    else if (!strcmp(key, "staged_server")) t.staged_server = value != 0;
     else if (!strcmp(key, "zero_copy_trace")) t.zero_copy_trace = value != 0;
     else if (!strcmp(key, "zero_copy_tickets")) t.zero_copy_tickets = value != 0;
     else if (!strcmp(key, "zero_copy_spin")) t.zero_copy_spin = value != 0;
@@ -183,7 +184,15 @@ extern "C" int mi_blur_interleaved_to_planar(const uint8_t *d_interleaved, uint8
 // ----------------------------------------------------------------------------------
 namespace {
 
-constexpr int STAGING_COPY_THREADS = 4;     // pageable caller memory <-> pinned staging (one thread moves ~10 GB/s)
+static int staging_threads_env()
+{
+    const char *e = getenv("MI_BLUR_STAGING_THREADS");
+    const int n = e ? atoi(e) : 0;
+    return n >= 1 && n <= 64 ? n : 8;
+}
+// pageable caller memory <-> pinned staging: one thread moves ~10 GB/s, the link wants ~45 GB/s each way (8 threads: 220 k
+// img/s at batch 35 and 500; 4: 145-180 k; MI_BLUR_STAGING_THREADS overrides)
+static const int STAGING_COPY_THREADS = staging_threads_env();
 
 struct Slot {
     hipStream_t stream = nullptr;
@@ -497,6 +506,8 @@ static int finish_slot(mi_blur_ctx *c, Slot &s)
             if (e > from) c->tm.kernel_ms += (double)(e - from) / 1e5;
             z.covered = std::max(z.covered, e);
         }
+        if (s.out_staged)                                        // the server wrote the slot's staging: scatter to the caller's memory
+            copy_blocks(s.user_out, s.out_stride, s.h_out, s.out_band, s.out_band, s.out_n, STAGING_COPY_THREADS);
         s.zero_copy = false; s.zc_server = false; s.busy = false;
         return MI_BLUR_OK;
     }
@@ -805,6 +816,34 @@ static int submit_common(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_o
         if (!in_pinned) {                       // pageable caller memory: gather into the slot's pinned staging
             copy_blocks(s.h_in, band_in, host_in, in_stride, band_in, n_images, STAGING_COPY_THREADS);
             src = s.h_in; src_stride = band_in;
+        }
+        // Pageable caller memory (the reference's malloc'd batch buffers, kept as they are): the staging buffers ARE pinned, so
+        // the batch server takes the batch from them in place — staging in -> blur -> staging out as one kernel stream over the
+        // link — instead of a DMA copy each way around a launch (copies in both directions at once collapse to ~28 GB/s in
+        // total on this platform, profiles/r01_pcie_probe.txt).  What stays is the host's own gather / scatter between the
+        // caller's memory and the staging.
+        if (tun.zero_copy && tun.zero_copy_server && tun.staged_server) {
+            const uint8_t *zin = pinned_device_ptr(src);
+            uint8_t *zout = pinned_device_ptr(s.out_staged ? s.h_out : host_out);
+            const size_t zout_stride = s.out_staged ? band_out : out_stride;
+            if (zin && zout) {
+                LaunchDesc d{};
+                d.in = zin; d.out = zout; d.width = c->W; d.band_rows = band_rows; d.channels = c->C;
+                d.radius = c->R; d.n_images = n_images; d.y0 = y0; d.y1 = y1; d.variant = MI_BLUR_VARIANT_AUTO;
+                d.in_stride = (long long)src_stride; d.out_stride = (long long)zout_stride;
+                rc = zc_server_submit(c, s, d, tun);
+                if (rc == MI_BLUR_OK) {
+                    s.zero_copy = true; s.busy = true;
+                    c->tm.bytes_h2d += in_bytes; c->tm.bytes_d2h += out_bytes;
+                    c->tm.bytes_alg += 2ull * out_bytes;
+                    c->tm.images += (uint64_t)n_images;
+                    c->tm.launches += 1;
+                    c->zero_copy_launches += 1;
+                    return MI_BLUR_OK;
+                }
+                if (rc != MI_BLUR_ERR_UNSUPPORTED) return rc;
+                s.zc_server = false;
+            }
         }
         HIP_TRY(hipEventRecord(s.ev[0], s.stream));
         if (src_stride == band_in)

@@ -102,6 +102,10 @@ const char *mi_blur_last_kernel(void);
  *   "resident_place_trials" 4 (default): see mi_blur_resident_alloc
  *   "zero_copy_spin"    0 (default) = a wait for a batch of the server spins ~20 us, then sleeps in 20 us steps (the core is
  *                      free for the threads that build the next batch); 1 = spin + yield only
+ *   "staged_server"    1 (default) | 0: submits of PAGEABLE caller memory (the reference's malloc'd batch buffers) are gathered into
+ *                       the slot's pinned staging and blurred there in place by the batch server (staging in -> staging out over the
+ *                       link, 220 k img/s at batch 35 and 500) instead of a DMA copy each way around a launch (120-158 k).
+ *                       MI_BLUR_STAGING_THREADS (default 8) = host threads of the gather / scatter
  *   "zero_copy_trace"   0 (default) | 1 = the server's workers stamp their phases (mi_blur_debug_zc_trace)
  *   "zero_copy_debug_base"  test hook, 0 (default) | n: a context's server starts n batches / 7n tiles short of 2^32, so the
  *                       wrap of its 32-bit batch and tile numbers (80 minutes into a continuous stream) is reached at once
@@ -259,7 +263,8 @@ void mi_blur_reset_timing(mi_blur_ctx *ctx);
  * reference prints once per run (heterogeneous_blur.c:541-579) becomes available per batch, which is
  * what continuous CPU/GPU rebalancing needs (`both auto`). */
 int mi_blur_get_timing(mi_blur_ctx *ctx, mi_blur_timing *timing);
-/* How many of the context's submits so far ran zero-copy (see mi_blur_host_alloc). */
+/* How many of the context's submits so far were blurred in place over the host link: pinned caller buffers (see
+ * mi_blur_host_alloc), and pageable ones by way of the slot's pinned staging ("staged_server", default on). */
 uint64_t mi_blur_zero_copy_launches(mi_blur_ctx *ctx);
 
 /* ------------------------------------------------------------------------

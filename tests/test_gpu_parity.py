@@ -56,6 +56,7 @@ def reset_opts(L):
     L.mi_blur_set_option(b"prefer_direct", 1)
     L.mi_blur_set_option(b"direct_bh", 8)
     L.mi_blur_set_option(b"zero_copy_server", 1)
+    L.mi_blur_set_option(b"staged_server", 1)
     L.mi_blur_set_option(b"zero_copy_workers", 48)
     L.mi_blur_set_option(b"zero_copy_idle_us", 300)
     L.mi_blur_set_option(b"zero_copy_budget", 256)
@@ -404,15 +405,27 @@ def test_context_submit_pageable_and_pinned(pkg, L, O, torch_cuda):
     host = O.lcg_stream(n, h, w, c)
     want = O.blur_batch(host, 1)
     with pkg.Context(0, w, h, c, 1, max_batch=n, n_slots=2) as ctx:
-        out = np.zeros_like(host)
-        ctx.submit(host.ctypes.data, out.ctypes.data, n)                     # pageable caller memory
-        ctx.submit(host[:10].ctypes.data, out[:10].ctypes.data, 10)          # second slot, overlapping range rewritten
-        tm = ctx.sync()
-        assert np.array_equal(out, want)
-        assert tm["images"] == n + 10 and tm["launches"] == 2
-        assert tm["kernel_ms"] > 0 and tm["h2d_ms"] > 0 and tm["d2h_ms"] > 0
-        assert tm["bytes_h2d"] == (n + 10) * h * w * c
-        assert L.mi_blur_zero_copy_launches(ctx.h) == 0                      # pageable memory is always staged
+        # pageable caller memory (the reference's malloc'd batch buffers) is gathered into the slot's pinned staging; from there
+        # the batch server takes it in place (default), or — "staged_server" 0 — a DMA copy each way around a launch
+        for staged_server in (1, 0):
+            pkg.check(L.mi_blur_set_option(b"staged_server", staged_server))
+            try:
+                out = np.zeros_like(host)
+                before = L.mi_blur_zero_copy_launches(ctx.h)
+                ctx.reset_timing()
+                ctx.submit(host.ctypes.data, out.ctypes.data, n)
+                ctx.submit(host[:10].ctypes.data, out[:10].ctypes.data, 10)          # second slot, overlapping range rewritten
+                tm = ctx.sync()
+                assert np.array_equal(out, want), staged_server
+                assert tm["images"] == n + 10 and tm["launches"] == 2 and tm["bytes_h2d"] == (n + 10) * h * w * c
+                if staged_server:
+                    assert L.mi_blur_last_kernel() == b"blur_server_kernel" and L.mi_blur_zero_copy_launches(ctx.h) - before == 2
+                    assert tm["kernel_ms"] > 0 and tm["h2d_ms"] == 0 and tm["d2h_ms"] == 0      # the transfer time IS the kernel bucket
+                else:
+                    assert L.mi_blur_zero_copy_launches(ctx.h) - before == 0
+                    assert tm["kernel_ms"] > 0 and tm["h2d_ms"] > 0 and tm["d2h_ms"] > 0
+            finally:
+                pkg.check(L.mi_blur_set_option(b"staged_server", 1))
         # pinned caller memory: the kernel works on it in place (zero-copy, default) or DMA goes straight from/to it
         nbytes = host.nbytes
         p_in, p_out = L.mi_blur_host_alloc(nbytes), L.mi_blur_host_alloc(nbytes)
@@ -447,9 +460,9 @@ def test_context_submit_pageable_and_pinned(pkg, L, O, torch_cuda):
         assert L.mi_blur_zero_copy_launches(ctx.h) - before == 1 and np.array_equal(own_out, want)
         pkg.check(L.mi_blur_host_unregister(own_in.ctypes.data)); pkg.check(L.mi_blur_host_unregister(own_out.ctypes.data))
         own_out[:] = 0
-        ctx.submit(own_in.ctypes.data, own_out.ctypes.data, n)                  # unregistered again: staged, same bytes
+        ctx.submit(own_in.ctypes.data, own_out.ctypes.data, n)                  # unregistered again: through the staging, same bytes
         ctx.sync()
-        assert L.mi_blur_zero_copy_launches(ctx.h) - before == 1 and np.array_equal(own_out, want)
+        assert L.mi_blur_zero_copy_launches(ctx.h) - before == 2 and np.array_equal(own_out, want)
         # Approach-2 bands through the context
         one = np.ascontiguousarray(host[0]); split = 39
         top, bot = np.zeros((split, w, c), np.uint8), np.zeros((h - split, w, c), np.uint8)
@@ -862,7 +875,10 @@ def test_submit_bands_strided_batch(pkg, L, O, torch_cuda):
                 tm = ctx.sync()
                 assert tm["launches"] == 2 and tm["images"] == 2 * n
                 # pinned + zero_copy: the strided bands are blurred in place in the caller's batch buffers
-                assert L.mi_blur_zero_copy_launches(ctx.h) == (2 if pinned is True else 0)
+                # pageable: through the pinned staging — the first band by the batch server, the second (another tile geometry
+                # than the running server's) by a DMA copy each way, unless it happens to share the geometry
+                zc = L.mi_blur_zero_copy_launches(ctx.h)
+                assert (zc == 2) if pinned is True else (zc == 0) if pinned == "staged" else zc in (1, 2)
                 if pinned:
                     got = np.ctypeslib.as_array((C.c_uint8 * host.nbytes).from_address(p_out)).reshape(host.shape).copy()
                     L.mi_blur_host_free(p_in); L.mi_blur_host_free(p_out)

@@ -22,6 +22,8 @@ def main():
     n_sub = int(sys.argv[3]) if len(sys.argv) > 3 else 60
     pkg = entry.load_package()
     L = pkg.lib()
+    L.mi_blur_bind_thread_to_device(0)                         # as the hosts' feeder threads do: this thread, the helper threads it
+                                                                # starts and the pages it touches first stay on the GPU's socket
     opts = [a.split("=") for a in sys.argv[4:]]                  # key=value pairs for mi_blur_set_option; arena=MiB is the probe's own
     arena_mib = 0
     shape = (256, 256)
