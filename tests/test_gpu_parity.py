@@ -513,6 +513,48 @@ def test_zero_copy_capped_grid_and_streams(pkg, L, O, torch_cuda, radius):
             L.mi_blur_host_free(pi); L.mi_blur_host_free(po)
 
 
+def test_batch_server_mixed_pinned_and_pageable_submits(pkg, L, O, torch_cuda):
+    """One context, one server: submits whose buffers are pinned (blurred in place), pageable (gathered into the slot's pinned
+    staging, blurred there, scattered back when the slot is harvested) and half-and-half (pinned in / pageable out and the
+    reverse), interleaved at random with random batch sizes; every batch verified and poisoned before its buffers are reused."""
+    h, w, c, n, radius = 96, 320, 3, 9, 1
+    nbuf = 4
+    host = O.lcg_stream(nbuf * n, h, w, c, first_index=40)
+    want = O.blur_batch(host, radius)
+    nbytes = n * h * w * c
+    pin = [(L.mi_blur_host_alloc(nbytes), L.mi_blur_host_alloc(nbytes)) for _ in range(nbuf)]
+    pag = [(np.ascontiguousarray(host[k * n:(k + 1) * n]).copy(), np.full((n, h, w, c), 0xEE, np.uint8)) for k in range(nbuf)]
+    as_np = lambda ptr: np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(ptr)).reshape(n, h, w, c)
+    try:
+        for k, (pi, po) in enumerate(pin):
+            C.memmove(pi, host[k * n:(k + 1) * n].ctypes.data, nbytes)
+            C.memset(po, 0xEE, nbytes)
+        rng = np.random.default_rng(99)
+        with pkg.Context(0, w, h, c, radius, max_batch=n, n_slots=nbuf) as ctx:
+            kinds, sizes = [None] * nbuf, [n] * nbuf
+            out_of = lambda k: as_np(pin[k][1]) if kinds[k][1] == "pin" else pag[k][1]
+            for i in range(160):
+                k = i % nbuf
+                if i >= nbuf:
+                    ctx.wait_oldest()
+                    got = out_of(k)
+                    assert np.array_equal(got[:sizes[k]], want[k * n:k * n + sizes[k]]), (i, kinds[k])
+                    assert bool((got[sizes[k]:] == 0xEE).all()), (i, kinds[k])
+                    got[:] = 0xEE
+                kinds[k] = (str(rng.choice(["pin", "page"])), str(rng.choice(["pin", "page"])))
+                sizes[k] = int(rng.integers(1, n + 1))
+                src = pin[k][0] if kinds[k][0] == "pin" else pag[k][0].ctypes.data
+                dst = pin[k][1] if kinds[k][1] == "pin" else pag[k][1].ctypes.data
+                ctx.submit(src, dst, sizes[k])
+            ctx.sync()
+            for k in range(nbuf):
+                assert np.array_equal(out_of(k)[:sizes[k]], want[k * n:k * n + sizes[k]]), k
+            assert L.mi_blur_zero_copy_launches(ctx.h) == 160 and L.mi_blur_last_kernel() == b"blur_server_kernel"
+    finally:
+        for (pi, po) in pin:
+            L.mi_blur_host_free(pi); L.mi_blur_host_free(po)
+
+
 @pytest.mark.parametrize("base,budget", [(40, 256), (40, 7), (3, 256), (100, 5)])
 def test_batch_server_number_wrap(pkg, L, O, torch_cuda, base, budget):
     """The server numbers batches and tiles in 32 bits through the life of a context; a continuous batch-35 stream of 256x256
