@@ -162,6 +162,13 @@ int main(int argc, char **argv)
     printf("\nKernel objects created (code objects are embedded in libmi_blur.so; nothing is read from the CWD)\n\n");
 
     // ---------------- buffers (heterogeneous_blur.c:330-357,431-437): pinned, `nslots` rotating sets
+    // (--malloc: ordinary malloc'd memory, as the reference allocates them — every submit then goes through the library's pinned staging)
+    auto batch_alloc = [&](int ordinal, size_t bytes) -> uint8_t * {
+        if (opt.malloc_buffers) return (uint8_t *)malloc(bytes);
+        return (uint8_t *)(ordinal >= 0 ? mi_blur_host_alloc_on(ordinal, bytes) : mi_blur_host_alloc(bytes));
+    };
+    auto batch_free = [&](uint8_t *p) { if (opt.malloc_buffers) free(p); else mi_blur_host_free(p); };
+    if (opt.malloc_buffers) printf("Batch buffers: malloc (pageable), as in the reference; submits are staged through pinned memory by the library\n");
     printf("Allocating device buffers...\n");
     std::vector<uint8_t *> batch_input(nslots, nullptr), batch_output(nslots, nullptr);
     std::vector<std::vector<uint8_t *>> gin(G), gout(G);               // per_gpu_feeders: GPU g's own rotating buffer sets
@@ -169,15 +176,15 @@ int main(int argc, char **argv)
         for (int g = 0; g < G; g++) {
             const size_t share = (size_t)share_max;
             for (int s = 0; s < nslots; s++) {
-                gin[g].push_back((uint8_t *)mi_blur_host_alloc_on(hip_ordinal(g), share * image_size));
-                gout[g].push_back((uint8_t *)mi_blur_host_alloc_on(hip_ordinal(g), share * image_size));
+                gin[g].push_back(batch_alloc(hip_ordinal(g), share * image_size));
+                gout[g].push_back(batch_alloc(hip_ordinal(g), share * image_size));
                 if (!gin[g].back() || !gout[g].back()) { printf("Error: Failed to allocate batch memory\n"); return -1; }
             }
         }
     } else if (!opt.resident) {
         for (int s = 0; s < nslots; s++) {
-            batch_input[s] = (uint8_t *)mi_blur_host_alloc((size_t)BATCH_SIZE * image_size);
-            batch_output[s] = (uint8_t *)mi_blur_host_alloc((size_t)BATCH_SIZE * image_size);
+            batch_input[s] = batch_alloc(-1, (size_t)BATCH_SIZE * image_size);
+            batch_output[s] = batch_alloc(-1, (size_t)BATCH_SIZE * image_size);
             if (!batch_input[s] || !batch_output[s]) { printf("Error: Failed to allocate batch memory\n"); return -1; }
         }
     } else {
@@ -252,7 +259,7 @@ int main(int argc, char **argv)
                     mi_blur_shard_range(BATCH_SIZE, g, G, &b, &e);
                     const int nw = (int)std::min<long long>(e - b, 4);
                     if (nw > 0) {
-                        rep.run(gin[g][0], original_image, image_size, nw, true);
+                        rep.run(gin[g][0], original_image, image_size, nw, !opt.malloc_buffers);
                         ok(mi_blur_submit(ctx, gin[g][0], gout[g][0], nw)) && ok(mi_blur_sync(ctx, nullptr));
                         mi_blur_reset_timing(ctx);
                     }
@@ -279,7 +286,7 @@ int main(int argc, char **argv)
                     int done = 0, pieces = 0;
                     while (done < n && feed_rc[g] == MI_BLUR_OK) {     // create batch image stream (:439-442) and hand it over, piece by piece
                         const int m = std::min(feed_piece, n - done);
-                        rep.run(gin[g][s] + (size_t)done * image_size, original_image, image_size, m, true);
+                        rep.run(gin[g][s] + (size_t)done * image_size, original_image, image_size, m, !opt.malloc_buffers);
                         ok(mi_blur_submit(ctx, gin[g][s] + (size_t)done * image_size, gout[g][s] + (size_t)done * image_size, m));
                         done += m; pieces++;
                     }
@@ -374,7 +381,7 @@ int main(int argc, char **argv)
                     first_output.assign(batch_output[s], batch_output[s] + image_size);
             }
             // create batch image stream (contiguous) — heterogeneous_blur.c:439-442
-            replicate.run(batch_input[s], original_image, image_size, batch_count, mode == 2);
+            replicate.run(batch_input[s], original_image, image_size, batch_count, mode == 2 && !opt.malloc_buffers);
 
             int num_images_cpu = 0, num_images_gpu = 0;
             mi_blur_a1_partition(mode, batch_count, gpu_ratio, &num_images_cpu, &num_images_gpu);
@@ -483,8 +490,8 @@ int main(int argc, char **argv)
                    time_total_processing, total_images_cpu, tcpu, total_images_gpu, tgpu, cmp, thr, optimal_gpu_ratio, rf, G);
 
     // ---------------- cleanup (heterogeneous_blur.c:727-747)
-    for (int s = 0; s < nslots; s++) { mi_blur_host_free(batch_input[s]); mi_blur_host_free(batch_output[s]); }
-    for (int g = 0; g < G; g++) for (size_t s = 0; s < gin[g].size(); s++) { mi_blur_host_free(gin[g][s]); mi_blur_host_free(gout[g][s]); }
+    for (int s = 0; s < nslots; s++) { if (batch_input[s]) batch_free(batch_input[s]); if (batch_output[s]) batch_free(batch_output[s]); }
+    for (int g = 0; g < G; g++) for (size_t s = 0; s < gin[g].size(); s++) { batch_free(gin[g][s]); batch_free(gout[g][s]); }
     if (cpu.ctx) mi_blur_destroy(cpu.ctx);
     for (auto &d : gpus) mi_blur_destroy(d.ctx);
     return 0;

@@ -167,6 +167,7 @@ struct Options {
                                          // heterogeneous_blur, 3 in split_image_blur, 2 for the CPU device alone
     int threads = 0;                     // --threads T  CPU device threads (0 = all cores)
     int host_threads = 4;                // --host-threads T  helper threads that build each batch's stream
+    bool malloc_buffers = false;         // --malloc     batch buffers from malloc (pageable), as the reference allocates them
     bool verbose = false;                // --verbose    per-batch progress lines (heterogeneous_blur.c:420,463,599)
     bool resident = false;               // --resident   device-resident stream (kernel-only)
     std::string csv;                     // --csv FILE   append one per_run.csv-style row
@@ -225,6 +226,7 @@ inline int parse_flags(int argc, char **argv, Options &o)
         else if (a == "--save-dir") o.save_dir = next("--save-dir");
         else if (a == "--planar-out") o.planar_out = true;
         else if (a == "--native-layout") o.native_layout = true;
+        else if (a == "--malloc") o.malloc_buffers = true;
         else if (a == "--transport") { o.transport = next("--transport"); if (o.transport != "rccl" && o.transport != "p2p" && o.transport != "pull" && o.transport != "peer") { printf("Error: --transport rccl|p2p|pull|peer\n"); exit(-1); } }
         else { printf("Error: unknown option %s\n", a.c_str()); exit(-1); }
     }

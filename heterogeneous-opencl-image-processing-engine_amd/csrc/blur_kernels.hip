@@ -1171,6 +1171,7 @@ static Tunables &tunables_storage()
         v.fused_tail = 30; v.fused_tail_blocks = 25;
         v.resident_place_trials = 4;
         if (const char *e = getenv("MI_BLUR_PLACE_TRIALS")) { const int r = atoi(e); if (r >= 0 && r <= 8) v.resident_place_trials = r; }
+        if (const char *e = getenv("MI_BLUR_STAGED_SERVER")) v.staged_server = atoi(e) != 0;
         if (const char *e = getenv("MI_BLUR_FUSED_TAIL")) { const int r = atoi(e); if (r >= 0 && r <= 500) v.fused_tail = r; }
         if (const char *e = getenv("MI_BLUR_STAGE")) v.stage_dma = strcmp(e, "reg") != 0;
         if (const char *e = getenv("MI_BLUR_RPG")) { const int r = atoi(e); v.rpg = (r == 4 || r == 8 || r == 16) ? r : 0; }

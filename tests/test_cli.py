@@ -258,6 +258,12 @@ def test_a1_gpu_and_both_modes(apps, O, tmp_path):
     assert r.returncode == 0 and "Auto-calibrated GPU ratio:" in r.stdout, r.stdout + r.stderr
     assert "Auto ratio after" in r.stdout and "per-batch updates" in r.stdout, r.stdout    # keeps rebalancing per batch
     assert np.array_equal(read_ppm(tmp_path / "auto.ppm"), want)
+    # --malloc: the batch buffers are ordinary malloc'd memory, as the reference allocates them (heterogeneous_blur.c:431-432):
+    # every submit goes through the library's pinned staging (which the batch server blurs in place); same pixels, same report
+    for mode_args, fname in ((["gpu", "1.0", "35"], "gpu_m.ppm"), (["both", "0.728", "35"], "both_m.ppm"), (["gpu", "1.0", "500"], "gpu_m500.ppm")):
+        r = run([het] + mode_args + ["--image", "in.ppm", "--images", "500", "--malloc", "--save", fname], tmp_path)
+        assert r.returncode == 0 and "Batch buffers: malloc (pageable)" in r.stdout and "7. THROUGHPUT" in r.stdout, r.stdout + r.stderr
+        assert np.array_equal(read_ppm(tmp_path / fname), want), mode_args
     r = run([het, "gpu", "1.0", "35", "--size", "256x256", "--images", "5000", "--resident"], tmp_path)
     assert r.returncode == 0 and "9. MI355X KERNEL ROOFLINE" in r.stdout, r.stdout + r.stderr
     r = run([het, "gpu", "1.0", "35", "--size", "256x256", "--images", "5000", "--resident", "--fused"], tmp_path)
