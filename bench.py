@@ -36,7 +36,8 @@ At N=1 the a1 line also carries, measured after the timed region: `sustained_img
 fused pass complete: first / p50 / last batch, polled during >= 24 passes — the per-batch clFinish of
 heterogeneous_blur.c:538-539), `release_mode_us` (the same pass with the architectural release-ordered completion add), and
 `extra` = {one_launch_5000_images, hd1080_5x5 (configs[2]), a2_8192_1gpu (configs[4] at N=1), e2e_pcie_inclusive (host
-buffers in -> host buffers out, batch 35 and 500; comparable to the reference's wall clock, never `value`)}.
+buffers in -> host buffers out, batch 35 and 500 on pinned buffers and batch 35 on pageable (malloc'd) ones, the reference's own
+kind; comparable to the reference's wall clock, never `value`)}.
 At N>1 the a1 line carries BOTH multi-GPU configs: configs[3] is `value`; after its timed region the same ranks run
 configs[4] (`extra.a2_8192_rowsplit`: the 8192x8192x3 image row-split over the N GPUs, halo rows by RCCL send/recv, the
 plain step and the overlapped step both timed, `rccl_ranks` from the communicator).
@@ -479,12 +480,19 @@ def main() -> None:
                 "step_us": round(us, 2), "achieved_gbs": round(2.0 * H * pitch / us / 1e3, 1), "frac": frac_of(2.0 * H * pitch, us),
                 "img_s": round(steps / wall, 1), "out_fnv": fnv}
 
-    def point_e2e(w, h, c, radius, nb, nbatches) -> dict:
-        """Host buffers in -> host buffers out (zero-copy submits over PCIe), 4 rotating pinned buffer pairs."""
+    def point_e2e(w, h, c, radius, nb, nbatches, pageable=False) -> dict:
+        """Host buffers in -> host buffers out (zero-copy submits over PCIe), 4 rotating buffer pairs: pinned (mi_blur_host_alloc),
+        or — pageable — ordinary malloc'd memory as the reference allocates its batch buffers (heterogeneous_blur.c:431-432),
+        which the library gathers into pinned staging and scatters back."""
         NS = 4
         e2e = pkg.Context(local_rank, w, h, c, radius, max_batch=nb, n_slots=NS)
         nbytes = nb * h * w * c
-        bufs = [(L.mi_blur_host_alloc(nbytes), L.mi_blur_host_alloc(nbytes)) for _ in range(NS)]
+        keep = []
+        if pageable:
+            keep = [(np.zeros(nbytes, np.uint8), np.zeros(nbytes, np.uint8)) for _ in range(NS)]
+            bufs = [(a.ctypes.data, b.ctypes.data) for a, b in keep]
+        else:
+            bufs = [(L.mi_blur_host_alloc(nbytes), L.mi_blur_host_alloc(nbytes)) for _ in range(NS)]
         for (pi, _po) in bufs:
             L.mi_blur_fill_synthetic(pi, w, h, c, 0, nb, 4)
         warm_until = time.perf_counter() + SECONDARY_WARM_S       # filling the buffers left GPU and link idle: ramp both again
@@ -504,8 +512,12 @@ def main() -> None:
                "frac_of_link": round(nbatches * nbytes / dte / 1e9 / LINK_ONE_WAY_GBS, 3),
                "h2d_ms": round(te["h2d_ms"], 2), "kernel_ms": round(te["kernel_ms"], 2), "d2h_ms": round(te["d2h_ms"], 2)}
         e2e.close()
-        for (pi, po) in bufs:
-            L.mi_blur_host_free(pi); L.mi_blur_host_free(po)
+        if pageable:
+            res["buffers"] = "pageable (malloc'd), gathered into / scattered from the library's pinned staging on host threads"
+        else:
+            for (pi, po) in bufs:
+                L.mi_blur_host_free(pi); L.mi_blur_host_free(po)
+        del keep
         return res
 
     def guarded(name, fn):
@@ -1084,10 +1096,12 @@ def main() -> None:
             extra["a2_8192_1gpu"] = guarded("a2_8192_1gpu", lambda: point_a2_1gpu(300))
             extra["e2e_pcie_inclusive"] = {"batch_35": guarded("e2e batch 35", lambda: point_e2e(256, 256, 3, 1, 35, 143 * 4)),
                                            "batch_500": guarded("e2e batch 500", lambda: point_e2e(256, 256, 3, 1, 500, 40)),
+                                           "batch_35_pageable": guarded("e2e batch 35 pageable", lambda: point_e2e(256, 256, 3, 1, 35, 143 * 4, pageable=True)),
                                            "link_one_way_gbs": LINK_ONE_WAY_GBS,
                                            "note": "pinned host buffers in and out, the batch server's workgroups work on them in place over PCIe "
                                                    "(both directions at once; frac_of_link = each-way rate / the measured ONE-way DMA rate); "
-                                                   "comparable to the reference's wall clock (heterogeneous_blur.c:415,603)"}
+                                                   "comparable to the reference's wall clock (heterogeneous_blur.c:415,603); batch_35_pageable = the "
+                                                   "reference's own kind of batch buffers (malloc), unchanged: one host copy each way on top"}
         base_shape = (h, w, c, radius)
     else:   # a2: one 8192x8192x3 image, row-split, RCCL halo exchange
         r2 = run_a2(K, W, args.ramp_seconds)
