@@ -20,9 +20,13 @@ def main():
     pkg = entry.load_package()
     L = pkg.lib()
     O = entry.load_oracle()
+    mixed = False
     for a in sys.argv[2:]:
         k, v = a.split("=")
-        pkg.check(L.mi_blur_set_option(k.encode(), int(v)), k)
+        if k == "mixed":                 # mixed=1 (the probe's own): every submit draws pinned or pageable buffers for each side
+            mixed = int(v) != 0
+        else:
+            pkg.check(L.mi_blur_set_option(k.encode(), int(v)), k)
     h, w, c, n, nbuf, radius = 96, 320, 3, 12, 4, 1
     host = O.lcg_stream(nbuf * n, h, w, c, first_index=4242)
     want = O.blur_batch(host, radius)
@@ -32,6 +36,8 @@ def main():
     for k, (pi, po) in enumerate(bufs):
         C.memmove(pi, host[k * n:(k + 1) * n].ctypes.data, nbytes)
         C.memset(po, 0xEE, nbytes)
+    pag = [(np.ascontiguousarray(host[k * n:(k + 1) * n]).copy(), np.full((n, h, w, c), 0xEE, np.uint8)) for k in range(nbuf)]
+    out_pageable = [False] * nbuf
     rng = np.random.default_rng(99)
     ctx = pkg.Context(0, w, h, c, radius, max_batch=n, n_slots=nbuf)
     sizes = [n] * nbuf
@@ -41,15 +47,17 @@ def main():
         k = i % nbuf
         if i >= nbuf:
             ctx.wait_oldest()
-            got = as_np(bufs[k][1])
+            got = pag[k][1] if out_pageable[k] else as_np(bufs[k][1])
             if not (np.array_equal(got[:sizes[k]], want[k * n:k * n + sizes[k]]) and bool((got[sizes[k]:] == 0xEE).all())):
                 raise SystemExit(f"MISMATCH at batch {i - nbuf}")
-            C.memset(bufs[k][1], 0xEE, nbytes)
+            got[:] = 0xEE
         sizes[k] = int(rng.integers(1, n + 1))
         r = rng.random()
         if r < 0.02:
             time.sleep(float(rng.uniform(0.0001, 0.0008)))         # stalls around the idle time-out
-        ctx.submit(bufs[k][0], bufs[k][1], sizes[k])
+        in_pageable = mixed and rng.random() < 0.5
+        out_pageable[k] = mixed and rng.random() < 0.5
+        ctx.submit(pag[k][0].ctypes.data if in_pageable else bufs[k][0], pag[k][1].ctypes.data if out_pageable[k] else bufs[k][1], sizes[k])
         i += 1
         if time.perf_counter() - t_last > 10:
             print(f"  {i} batches verified so far", flush=True)
