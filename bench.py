@@ -1097,6 +1097,7 @@ def main() -> None:
             extra["e2e_pcie_inclusive"] = {"batch_35": guarded("e2e batch 35", lambda: point_e2e(256, 256, 3, 1, 35, 143 * 4)),
                                            "batch_500": guarded("e2e batch 500", lambda: point_e2e(256, 256, 3, 1, 500, 40)),
                                            "batch_35_pageable": guarded("e2e batch 35 pageable", lambda: point_e2e(256, 256, 3, 1, 35, 143 * 4, pageable=True)),
+                                           "hd1080_5x5_batch_8": guarded("e2e 1080p 5x5", lambda: point_e2e(1920, 1080, 3, 2, 8, 64)),   # configs[2] end to end
                                            "link_one_way_gbs": LINK_ONE_WAY_GBS,
                                            "note": "pinned host buffers in and out, the batch server's workgroups work on them in place over PCIe "
                                                    "(both directions at once; frac_of_link = each-way rate / the measured ONE-way DMA rate); "

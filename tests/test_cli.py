@@ -493,6 +493,7 @@ def test_bench_default_line_carries_every_single_gpu_config(pkg):
     assert 0 < ex["hd1080_5x5"]["frac"] <= 1 and 0 < ex["a2_8192_1gpu"]["frac"] <= 1
     assert ex["a2_8192_1gpu"]["out_fnv"] == "d283787bcc5b6dfd"             # tests/golden k3 8192x8192x3 (reference kernel)
     assert ex["e2e_pcie_inclusive"]["batch_35"]["img_s"] > 0 and ex["e2e_pcie_inclusive"]["batch_500"]["img_s"] > 0
+    assert ex["e2e_pcie_inclusive"]["hd1080_5x5_batch_8"]["img_s"] > 0 and ex["e2e_pcie_inclusive"]["hd1080_5x5_batch_8"]["kernel"] == "blur_server_kernel"
     pg = ex["e2e_pcie_inclusive"]["batch_35_pageable"]          # malloc'd caller buffers: through the pinned staging, served by the batch server
     assert pg["img_s"] > 0 and pg["kernel"] == "blur_server_kernel" and pg["zero_copy_submits"] > 0 and "pageable" in pg["buffers"]
     assert d["per_batch_launches"]["launches_per_step"] == 143
