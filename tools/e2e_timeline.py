@@ -30,7 +30,7 @@ def main():
     for k, v in opts:
         if k == "arena":
             arena_mib = int(v)
-        elif k in ("radius", "pageable"):                   # pageable=1: ordinary (malloc'd) caller buffers, the reference's own kind
+        elif k in ("radius", "pageable", "thp"):                   # pageable=1: ordinary (malloc'd) caller buffers, the reference's own kind
             pass
         elif k == "shape":                                 # shape=WxH (probe's own): e.g. a frame whose rows are not a multiple of 16 bytes
             shape = tuple(int(x) for x in v.split("x"))
@@ -45,6 +45,29 @@ def main():
         arena = L.mi_blur_host_alloc(total)
         base = (arena + (2 << 20) - 1) // (2 << 20) * (2 << 20)
         bufs = [(base + (2 * i) * step, base + (2 * i + 1) * step) for i in range(ns)]
+    elif int(dict(opts).get("thp", 0)):                     # thp=1: anonymous memory with transparent huge pages asked for, registered in place
+        import mmap
+        import ctypes
+        keep = []
+        bufs = []
+        step = (nbytes + (2 << 20) - 1) // (2 << 20) * (2 << 20)
+        for _ in range(ns):
+            pair = []
+            for _side in range(2):
+                m = mmap.mmap(-1, step + (2 << 20))
+                addr = ctypes.addressof(ctypes.c_char.from_buffer(m))
+                base = (addr + (2 << 20) - 1) // (2 << 20) * (2 << 20)
+                m.madvise(mmap.MADV_HUGEPAGE)
+                ctypes.memset(base, 1, step)                 # touch: pages (huge, if the kernel grants them) exist before they are pinned
+                pkg.check(L.mi_blur_host_register(base, nbytes))
+                keep.append(m)
+                pair.append(base)
+            bufs.append(tuple(pair))
+        try:
+            thp = [l for l in open("/proc/meminfo") if l.startswith("AnonHugePages")][0].split()[1]
+            print(f"AnonHugePages now {thp} kB; /sys/kernel/mm/transparent_hugepage/enabled: {open('/sys/kernel/mm/transparent_hugepage/enabled').read().strip()}", flush=True)
+        except Exception as e:
+            print("thp state:", e)
     elif int(dict(opts).get("pageable", 0)):
         import numpy as np
         keep = [(np.zeros(nbytes, np.uint8), np.zeros(nbytes, np.uint8)) for _ in range(ns)]
@@ -81,7 +104,7 @@ def main():
     ctx.close()
     if arena:
         L.mi_blur_host_free(arena)
-    elif int(dict(opts).get("pageable", 0)):
+    elif int(dict(opts).get("pageable", 0)) or int(dict(opts).get("thp", 0)):
         pass
     else:
         for (pi, po) in bufs:
