@@ -526,7 +526,9 @@ __global__ __launch_bounds__(256) void blur_tiled_x_kernel(const TiledParams p)
 // therefore sees batches complete in stream order while the GPU never pays a per-batch dispatch (4 us floor + ~3.5 us
 // of dispatch processing each).
 struct FusedParams {
-    unsigned *count;          // device, EIGHT counters per batch (spread by block number: less contention), zeroed before the launch
+    unsigned *count;          // device, `kcount` counters per batch (spread by block number: less contention), zeroed before the launch
+    unsigned kcount;          // 8 .. 256, a power of two: an add on a hot word costs ~200 ns of that word's time, so a batch of
+                              // thousands of tiles gets more words (8 serve the 140 tiles of a 35-image batch of 256x256 frames)
     unsigned tiles_per_batch; // batch_images * tiles per image
     int release;              // 1 = release-ordered completion add (agent scope): the architectural form, ~6x slower
     unsigned window;          // batches per window of the blockIdx -> tile map (>= 1)
@@ -556,8 +558,8 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(const TiledParams p, co
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                       // every wave of the block has drained (one atomic per block: the counters are hot spots)
     if (threadIdx.x == 0) {
-        if (f.release) __hip_atomic_fetch_add(&f.count[b * 8u + ((w ^ (w >> 3)) & 7u)], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        else __hip_atomic_fetch_add(&f.count[b * 8u + ((w ^ (w >> 3)) & 7u)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f.release) __hip_atomic_fetch_add(&f.count[b * f.kcount + ((w ^ (w >> 3)) & (f.kcount - 1u))], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_fetch_add(&f.count[b * f.kcount + ((w ^ (w >> 3)) & (f.kcount - 1u))], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -597,8 +599,8 @@ __global__ __launch_bounds__(256) void blur_fused_tail_kernel(const TiledParams 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (f.release) __hip_atomic_fetch_add(&f.count[b * 8u + ((w ^ (w >> 3)) & 7u)], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        else __hip_atomic_fetch_add(&f.count[b * 8u + ((w ^ (w >> 3)) & 7u)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f.release) __hip_atomic_fetch_add(&f.count[b * f.kcount + ((w ^ (w >> 3)) & (f.kcount - 1u))], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_fetch_add(&f.count[b * f.kcount + ((w ^ (w >> 3)) & (f.kcount - 1u))], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -606,7 +608,7 @@ __global__ __launch_bounds__(256) void blur_fused_tail_kernel(const TiledParams 
 // per_block; the wave then publishes (pass_seq, n + 1) in pinned host memory.  Lanes 0-7 read one counter each.  It ends with
 // the pass (every batch complete) or after ZC_HARD_TICKS — a pass that faulted never completes its counters.
 __global__ __launch_bounds__(64) void fused_watch_kernel(const unsigned *count, unsigned n_batches, unsigned tiles_per_batch, unsigned total_blocks,
-                                                         unsigned per_block, unsigned long long *host_word, unsigned pass_seq)
+                                                         unsigned per_block, unsigned long long *host_word, unsigned pass_seq, unsigned kcount)
 {
     const unsigned lane = threadIdx.x;
     const unsigned long long t0 = wall_clock64();
@@ -615,8 +617,8 @@ __global__ __launch_bounds__(64) void fused_watch_kernel(const unsigned *count, 
         const unsigned first = n * tiles_per_batch;
         const unsigned want = min(tiles_per_batch, total_blocks - first) * per_block;
         unsigned v = 0;
-        if (lane < 8) v = __hip_atomic_load(&count[8u * n + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+        for (unsigned k = lane; k < kcount; k += 64u) v += __hip_atomic_load(&count[kcount * n + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
         v = __builtin_amdgcn_readfirstlane(v);
         if ((int)(v - want) >= 0) {      // >=: the next pass (same counters, counting on) may already be adding to this batch
             n++;
@@ -1424,6 +1426,13 @@ static int launch_tiled(const LaunchDesc &d, const Tunables &tun, bool ragged = 
         const long long tpb = (long long)fused->batch_images * p.ntiles_y * p.nstrips;
         if (tpb <= 0 || tpb > 0x7fffffffLL) return MI_BLUR_ERR_INVALID;
         f.tiles_per_batch = (unsigned)tpb;
+        // counters per batch: at most ~64 adds per word and pass, within what the caller's counter array holds
+        unsigned k = 8;
+        while (k < 256u && tpb > 64ll * k) k *= 2;
+        const long long nbatches = ((long long)d.n_images + fused->batch_images - 1) / fused->batch_images;
+        while (k > 8u && fused->count_words > 0 && (long long)k * nbatches > fused->count_words) k /= 2;
+        f.kcount = k;
+        if (fused->counters_per_batch) *fused->counters_per_batch = k;
         if (fused->tiles_per_batch) *fused->tiles_per_batch = (unsigned)tpb;
         if (fused->waves_per_block) *fused->waves_per_block = 1;      // one count per block
         if (fused->total_blocks) *fused->total_blocks = (unsigned)nblocks;
@@ -1506,10 +1515,10 @@ int zc_launch_server(const ZcGeometry &geo, ZcHostCtl *ctl, ZcDevCtl *dev, unsig
 }
 
 int launch_fused_watch(const unsigned *count, unsigned n_batches, unsigned tiles_per_batch, unsigned total_blocks, unsigned per_block,
-                       unsigned long long *host_word, unsigned pass_seq, hipStream_t stream)
+                       unsigned long long *host_word, unsigned pass_seq, hipStream_t stream, unsigned counters_per_batch)
 {
-    if (!count || !host_word || n_batches == 0 || tiles_per_batch == 0) return MI_BLUR_ERR_INVALID;
-    hipLaunchKernelGGL(fused_watch_kernel, dim3(1), dim3(64), 0, stream, count, n_batches, tiles_per_batch, total_blocks, per_block, host_word, pass_seq);
+    if (!count || !host_word || n_batches == 0 || tiles_per_batch == 0 || counters_per_batch < 8 || (counters_per_batch & (counters_per_batch - 1))) return MI_BLUR_ERR_INVALID;
+    hipLaunchKernelGGL(fused_watch_kernel, dim3(1), dim3(64), 0, stream, count, n_batches, tiles_per_batch, total_blocks, per_block, host_word, pass_seq, counters_per_batch);
     return hip_status(hipGetLastError());
 }
 

@@ -28,8 +28,8 @@ struct LaunchDesc {
 int launch(const LaunchDesc &d);
 
 // Fused stream (blur_fused_kernel): one dispatch over d.n_images images whose blocks are ordered in batches of
-// batch_images; every block of batch b adds *waves_per_block (1) to one of count[8b .. 8b+7] (device, zeroed by the
-// caller) after its stores have drained, so batch b is complete when those eight sum to its blocks (geometry outputs:
+// batch_images; every block of batch b adds *waves_per_block (1) to one of count[kb .. kb+k-1], k = *counters_per_batch
+// (device, zeroed by the caller) after its stores have drained, so batch b is complete when those k sum to its blocks (geometry outputs:
 // a full batch has *tiles_per_batch blocks, the last one what is left of *total_blocks).
 // Aligned tiled shapes only (MI_BLUR_ERR_UNSUPPORTED otherwise).
 // geometry_only: fill the geometry outputs for these knobs and return without launching (the caller decides from them
@@ -40,13 +40,15 @@ struct FusedDesc {
     unsigned *count; int batch_images; unsigned *tiles_per_batch, *waves_per_block, *total_blocks;
     const Tunables *tun; bool geometry_only;
     unsigned *tail_ctr;     // device word, zero between passes: ticket counter of the pass's dynamic tail ("fused_tail"); nullptr = none
+    long long count_words;  // how many words `count` holds (0 = at least 8 per batch, the minimum)
+    unsigned *counters_per_batch;   // geometry output: counters each batch uses (8 .. 256; count[k * b .. k * b + k - 1] belong to batch b)
 };
 int launch_fused(const LaunchDesc &d, const FusedDesc &f);
 // Watcher of one fused pass (fused_watch_kernel, one wave on a stream of its own): follows the per-batch counters and keeps
 // *host_word (pinned host memory) = (pass_seq << 32) | leading batches complete, so the host reads a batch's completion
 // from its own memory instead of copying the counters back.  Ends when all n_batches are complete (or after a hard limit).
 int launch_fused_watch(const unsigned *count, unsigned n_batches, unsigned tiles_per_batch, unsigned total_blocks, unsigned per_block,
-                       unsigned long long *host_word, unsigned pass_seq, hipStream_t stream);
+                       unsigned long long *host_word, unsigned pass_seq, hipStream_t stream, unsigned counters_per_batch);
 
 // Planar (CImg storage: plane c of image i at (i*C + c)*W*H) <-> interleaved repack, layout_kernels.hip.
 int launch_planar_to_interleaved(const uint8_t *src, uint8_t *dst, int width, int height, int channels, int n_images, hipStream_t s);

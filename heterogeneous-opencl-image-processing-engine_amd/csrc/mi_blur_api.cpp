@@ -260,6 +260,7 @@ struct mi_blur_ctx {
     unsigned *fused_count = nullptr, *fused_host = nullptr;    // device counters; pinned host copy for polling
     int fused_cap = 0, fused_batches = 0;
     unsigned fused_tpb = 0, fused_wpb = 0, fused_blocks = 0;     // geometry of the latest fused pass
+    unsigned fused_k = 8;                                        // ... and how many counters each of its batches uses (8 .. 256)
     int fused_n = 0, fused_batch = 0;                            // its (n_images, batch): same again = counters keep counting up
     unsigned fused_passes = 0;                                   // passes accumulated in the counters since they were zeroed
     hipStream_t fused_poll = nullptr;
@@ -1229,22 +1230,22 @@ extern "C" int mi_blur_resident_run_fused(mi_blur_ctx *c, int n_images, int batc
     // The launch geometry (blocks per batch) depends on the tuning knobs as well as on the shape: take ONE copy of the
     // knobs, ask for the geometry first, launch with the same copy.
     const Tunables tun = tunables();
-    unsigned tpb = 0, wpb = 0, blocks = 0;
-    FusedDesc f{c->fused_count, batch, &tpb, &wpb, &blocks, &tun, true, c->fused_count + 8 * (size_t)c->fused_cap};
+    unsigned tpb = 0, wpb = 0, blocks = 0, kcnt = 8;
+    FusedDesc f{c->fused_count, batch, &tpb, &wpb, &blocks, &tun, true, c->fused_count + 8 * (size_t)c->fused_cap, 8ll * c->fused_cap, &kcnt};
     int rc = launch_fused(d, f);
     if (rc) return rc;
     // Repeated passes of the same shape AND geometry do not zero the counters (that would be one more dispatch per
     // pass): every pass adds the same amounts, so batch b of pass p is complete when its counters sum to p x (its blocks).
-    if (n_images == c->fused_n && batch == c->fused_batch && tpb == c->fused_tpb && wpb == c->fused_wpb &&
+    if (n_images == c->fused_n && batch == c->fused_batch && tpb == c->fused_tpb && wpb == c->fused_wpb && kcnt == c->fused_k &&
         blocks == c->fused_blocks && c->fused_passes > 0 && c->fused_passes < (1u << 20)) {
         c->fused_passes += 1;
     } else {
         // the counters are about to be zeroed: a watcher of the previous pass must have seen that pass's last counts first
         // (it ends with its pass; zeros under it would leave it waiting for its hard limit)
         if (c->fused_watched && c->fused_watch) HIP_TRY(hipStreamSynchronize(c->fused_watch));
-        HIP_TRY(hipMemsetAsync(c->fused_count, 0, sizeof(unsigned) * 8 * (size_t)nb, s.stream));
+        HIP_TRY(hipMemsetAsync(c->fused_count, 0, sizeof(unsigned) * (size_t)kcnt * (size_t)nb, s.stream));
         c->fused_n = n_images; c->fused_batch = batch; c->fused_passes = 1;
-        c->fused_tpb = tpb; c->fused_wpb = wpb; c->fused_blocks = blocks;
+        c->fused_tpb = tpb; c->fused_wpb = wpb; c->fused_blocks = blocks; c->fused_k = kcnt;
     }
     c->fused_batches = nb;
     c->fused_watched = false;
@@ -1259,7 +1260,7 @@ extern "C" int mi_blur_resident_run_fused(mi_blur_ctx *c, int n_images, int batc
             HIP_TRY(hipHostGetDevicePointer((void **)&c->fused_word_dev, c->fused_word, 0));
         }
         c->fused_watch_seq += 1;
-        rc = launch_fused_watch(c->fused_count, (unsigned)nb, tpb, blocks, wpb * c->fused_passes, c->fused_word_dev, c->fused_watch_seq, c->fused_watch);
+        rc = launch_fused_watch(c->fused_count, (unsigned)nb, tpb, blocks, wpb * c->fused_passes, c->fused_word_dev, c->fused_watch_seq, c->fused_watch, c->fused_k);
         if (rc) return rc;
         c->fused_watched = true;
     }
@@ -1298,14 +1299,15 @@ extern "C" int mi_blur_resident_batches_done(mi_blur_ctx *c)
     }
     // read the counters on a stream of their own (the pass may still be running on the compute stream)
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemcpyAsync(c->fused_host, c->fused_count, sizeof(unsigned) * 8 * (size_t)c->fused_batches, hipMemcpyDeviceToHost, c->fused_poll));
+    const unsigned K = c->fused_k;
+    HIP_TRY(hipMemcpyAsync(c->fused_host, c->fused_count, sizeof(unsigned) * (size_t)K * (size_t)c->fused_batches, hipMemcpyDeviceToHost, c->fused_poll));
     HIP_TRY(hipStreamSynchronize(c->fused_poll));
     int n = 0;
     for (; n < c->fused_batches; n++) {
         const unsigned first = (unsigned)n * c->fused_tpb;
         const unsigned blocks = std::min(c->fused_tpb, c->fused_blocks - first);
         unsigned sum = 0;
-        for (int k = 0; k < 8; k++) sum += c->fused_host[8 * n + k];
+        for (unsigned k = 0; k < K; k++) sum += c->fused_host[(size_t)K * n + k];
         if (sum != blocks * c->fused_wpb * c->fused_passes) break;
     }
     return n;

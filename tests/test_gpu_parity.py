@@ -1392,6 +1392,34 @@ def test_fused_stream_dynamic_tail(pkg, L, O, torch_cuda):
                 pkg.check(L.mi_blur_set_option(b"fused_release", 0))
 
 
+def test_fused_stream_big_batches(pkg, L, O, torch_cuda):
+    """A batch of thousands of tiles spreads its completion count over more words than a small one (8 .. 256 per batch: an add
+    on a hot word costs ~200 ns of that word's time — with eight words a 1080p pass in batches of 35 ran 223 us instead of 138).
+    Every image equals the oracle and every batch is reported exactly when complete, through the counter read-back and through
+    a watcher, over repeated passes and across changes of batch size (= of the counter layout) on one context."""
+    h, w, c, r, n = 64, 64, 3, 1, 9000                        # one tile per image
+    src = O.lcg_stream(n, h, w, c, first_index=21)
+    want = O.blur_batch(src, r)
+    with pkg.Context(0, w, h, c, r, max_batch=1, n_slots=1) as ctx:
+        ctx.resident_alloc(n)
+        ctx.resident_fill_synthetic(21)
+        for batch in (35, 4000, 600, 9000, 35, 1100):             # 8, 64, 16, 256, 8, 32 counters per batch
+            nb = (n + batch - 1) // batch
+            for rep in range(3):
+                ctx.resident_run_fused(n, batch, watch=(rep == 1))
+                seen = [ctx.resident_batches_done() for _ in range(20)]
+                ctx.sync()
+                seen.append(ctx.resident_batches_done())
+                assert all(0 <= a <= b2 <= nb for a, b2 in zip(seen, seen[1:])) and seen[-1] == nb, (batch, rep, seen)
+            out = np.zeros_like(src)
+            ctx.resident_download(0, out.ctypes.data, n)
+            assert np.array_equal(out, want), batch
+        # a short pass after a long one: fewer batches, other layout; the count of the short pass is its own
+        ctx.resident_run_fused(700, 300)
+        ctx.sync()
+        assert ctx.resident_batches_done() == 3
+
+
 def test_fused_stream_random_shapes(pkg, L, O, torch_cuda):
     """Seeded sweep of the fused stream: aligned shapes, C = 1..4, both radii, batch sizes that do and do not divide the
     stream, one or several strips per row, fewer tiles per batch than XCDs and many more."""
