@@ -281,8 +281,12 @@ struct __attribute__((packed, aligned(1))) Unaligned2 { uint16_t v; };
 
 // RAG output: a whole chunk as one unaligned 16-byte store, a row's partial last chunk as the 8/4/2/1-byte
 // pieces of the n (< 16) bytes that exist — the byte after them belongs to the next row.
+__device__ __forceinline__ void store16_write_through(uint8_t *q, u32x4 v);
+__device__ __forceinline__ void store_chunk_ragged_wt(uint8_t *q, u32x4 v, int n);
+template <bool WT = false>
 __device__ __forceinline__ void store_chunk_ragged(uint8_t *q, u32x4 v, int n)
 {
+    if constexpr (WT) { store_chunk_ragged_wt(q, v, n); return; }
     if (n >= 16) { reinterpret_cast<Unaligned16 *>(q)->v = v; return; }
     if (n & 8) { u32x2 t; t.x = v.x; t.y = v.y; reinterpret_cast<Unaligned8 *>(q)->v = t; q += 8; v.x = v.z; v.y = v.w; }
     if (n & 4) { reinterpret_cast<Unaligned4 *>(q)->v = v.x; q += 4; v.x = v.y; }
@@ -322,6 +326,20 @@ __device__ __forceinline__ void store16_write_through(uint8_t *q, u32x4 v)
     // s_nop: a store of more than 8 bytes needs two wait states before a VALU may overwrite its data registers; the
     // compiler's hazard pass does not look inside inline asm
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(q), "v"(v) : "memory");
+}
+
+// The ragged store written through L2 (fused stream on rows that are not a multiple of 16 bytes): every piece carries sc1.
+__device__ __forceinline__ void store_chunk_ragged_wt(uint8_t *q, u32x4 v, int n)
+{
+    if (n >= 16) { store16_write_through(q, v); return; }      // the hardware splits an unaligned 16-byte store where it must
+    if (n & 8) {
+        u32x2 t; t.x = v.x; t.y = v.y;
+        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(q), "v"(t) : "memory");
+        q += 8; v.x = v.z; v.y = v.w;
+    }
+    if (n & 4) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(q), "v"(v.x) : "memory"); q += 4; v.x = v.y; }
+    if (n & 2) { asm volatile("global_store_short %0, %1, off sc1" ::"v"(q), "v"(v.x) : "memory"); q += 2; v.x >>= 16; }
+    if (n & 1) asm volatile("global_store_byte %0, %1, off sc1" ::"v"(q), "v"(v.x) : "memory");
 }
 
 // One workgroup's tile (tile number L of the launch).  Threads may return early; the only barrier is after staging.
@@ -427,7 +445,7 @@ __device__ __forceinline__ void tiled_tile(const TiledParams &p, unsigned L, Hoo
         for (int r = 0; r < RPG; r++)
             if (r0 + r < rows_out) {
                 const u32x4 v = *reinterpret_cast<const u32x4 *>(lp + (r + R) * lrow);
-                if constexpr (RAG) store_chunk_ragged(op + (size_t)r * (size_t)p.pitch, v, (x0c + col) == p.cpr - 1 ? p.tail : 16);
+                if constexpr (RAG) store_chunk_ragged<WT>(op + (size_t)r * (size_t)p.pitch, v, (x0c + col) == p.cpr - 1 ? p.tail : 16);
                 else *reinterpret_cast<u32x4 *>(op + (size_t)r * (size_t)p.pitch) = v;
             }
         return;
@@ -466,7 +484,7 @@ __device__ __forceinline__ void tiled_tile(const TiledParams &p, unsigned L, Hoo
         }
         if (r0 + r < rows_out) {
             u32x4 v; v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
-            if constexpr (RAG) store_chunk_ragged(op + (size_t)r * (size_t)p.pitch, v, (x0c + col) == p.cpr - 1 ? p.tail : 16);
+            if constexpr (RAG) store_chunk_ragged<WT>(op + (size_t)r * (size_t)p.pitch, v, (x0c + col) == p.cpr - 1 ? p.tail : 16);
             else if constexpr (WT) store16_write_through(op + (size_t)r * (size_t)p.pitch, v);
             else *reinterpret_cast<u32x4 *>(op + (size_t)r * (size_t)p.pitch) = v;
         }
@@ -569,7 +587,9 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(const TiledParams p, co
 // (> ntail) extra blocks, which every XCD reaches when it is through its share; each draws a ticket and blurs that tail tile, or
 // leaves if the tail is gone.  An XCD that runs ahead so takes more of the tail, one that lags takes less.  Every extra
 // block draws exactly once, so the one that draws ticket nextra-1 knows it is the last and resets the counter for the next pass.
-template <int C, int R, int RPG>
+// RAG: rows that are not a multiple of 16 bytes (the ragged form of the tile code, its stores written through as well); those
+// passes always take this kernel, with an empty tail when they are short.
+template <int C, int R, int RPG, bool RAG = false>
 __global__ __launch_bounds__(256) void blur_fused_tail_kernel(const TiledParams p, const FusedParams f)
 {
     // (one call site of the tile code, reached by both kinds of block: with the tile code inside a ticket loop the same
@@ -595,7 +615,7 @@ __global__ __launch_bounds__(256) void blur_fused_tail_kernel(const TiledParams 
         tile = base + (nw >= 16 ? xcd_map(w, nw, p.xcd) : w);
     }
     const unsigned b = tile / f.tiles_per_batch;
-    tiled_tile<C, R, RPG, true, false, false, true>(p, tile);
+    tiled_tile<C, R, RPG, true, false, RAG, true>(p, tile);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1312,13 +1332,23 @@ static int launch_tiled_r(const LaunchDesc &d, const TiledParams &p, dim3 grid, 
 }
 
 template <int R>
-static int launch_fused_r(const LaunchDesc &d, const TiledParams &p, const FusedParams &f, dim3 grid, dim3 block, size_t lds, int rpg)
+static int launch_fused_r(const LaunchDesc &d, const TiledParams &p, const FusedParams &f, dim3 grid, dim3 block, size_t lds, int rpg, bool ragged = false)
 {
     auto go = [&](auto kernel) {
         if (d.start || d.stop) hipExtLaunchKernelGGL(kernel, grid, block, lds, d.stream, d.start, d.stop, 0, p, f);
         else hipLaunchKernelGGL(kernel, grid, block, lds, d.stream, p, f);
         return hip_status(hipGetLastError());
     };
+    if (ragged) {                                        // rows/thread 8, the tail kernel (its tail may be empty)
+        if (!f.tail_ctr || rpg != 8) return MI_BLUR_ERR_INVALID;
+        switch (d.channels) {
+        case 1: return go(blur_fused_tail_kernel<1, R, 8, true>);
+        case 2: return go(blur_fused_tail_kernel<2, R, 8, true>);
+        case 3: return go(blur_fused_tail_kernel<3, R, 8, true>);
+        case 4: return go(blur_fused_tail_kernel<4, R, 8, true>);
+        }
+        return MI_BLUR_ERR_INVALID;
+    }
     if (f.tail_ctr) {
         switch (d.channels * 10 + rpg) {
         case 14: return go(blur_fused_tail_kernel<1, R, 4>);
@@ -1414,7 +1444,7 @@ static int launch_tiled(const LaunchDesc &d, const Tunables &tun, bool ragged = 
     TiledParams p{};
     unsigned threads = 0;
     size_t lds = 0;
-    const int rpg = tiled_geometry(d, tun, ragged, fused != nullptr, 0, p, &threads, &lds);
+    const int rpg = tiled_geometry(d, tun, ragged, fused != nullptr, (fused && ragged) ? 8 : 0, p, &threads, &lds);
     if (rpg < 0) return rpg;
     const long long nblocks = p.nblocks;
     const dim3 grid((unsigned)nblocks), block(threads);
@@ -1447,10 +1477,15 @@ static int launch_tiled(const LaunchDesc &d, const Tunables &tun, bool ragged = 
                 f.nextra = ntail + (unsigned)((long long)ntail * std::max(10, tun.fused_tail_blocks) / 100);
                 g_last_kernel = "blur_fused_tail_kernel";
                 const dim3 tgrid(f.nstatic + f.nextra);
-                return R == 1 ? launch_fused_r<1>(d, p, f, tgrid, block, lds, rpg) : launch_fused_r<2>(d, p, f, tgrid, block, lds, rpg);
+                return R == 1 ? launch_fused_r<1>(d, p, f, tgrid, block, lds, rpg, ragged) : launch_fused_r<2>(d, p, f, tgrid, block, lds, rpg, ragged);
             }
         }
-        return R == 1 ? launch_fused_r<1>(d, p, f, grid, block, lds, rpg) : launch_fused_r<2>(d, p, f, grid, block, lds, rpg);
+        if (ragged) {      // ragged rows, no tail: the same kernel with every tile mapped to a block
+            if (!fused->tail_ctr) return MI_BLUR_ERR_UNSUPPORTED;
+            f.tail_ctr = fused->tail_ctr; f.ntail = 0; f.nstatic = (unsigned)nblocks; f.nextra = 0;
+            g_last_kernel = "blur_fused_tail_kernel";
+        }
+        return R == 1 ? launch_fused_r<1>(d, p, f, grid, block, lds, rpg, ragged) : launch_fused_r<2>(d, p, f, grid, block, lds, rpg, ragged);
     }
     return R == 1 ? launch_tiled_r<1>(d, p, grid, block, lds, rpg, tun.stage_dma != 0, ragged, tun.row_shuffle != 0, tun.experiment)
                   : launch_tiled_r<2>(d, p, grid, block, lds, rpg, tun.stage_dma != 0, ragged, tun.row_shuffle != 0, tun.experiment);
@@ -1528,8 +1563,11 @@ int launch_fused(const LaunchDesc &d, const FusedDesc &f)
     if (d.width <= 0 || d.band_rows <= 0 || d.n_images <= 0 || (d.radius != 1 && d.radius != 2)) return MI_BLUR_ERR_INVALID;
     if (d.y0 != 0 || d.y1 != d.band_rows || d.in_stride || d.out_stride) return MI_BLUR_ERR_INVALID;
     if ((long long)d.width * d.channels * d.band_rows > INT_MAX) return MI_BLUR_ERR_INVALID;
-    if (!tiled_eligible(d.in, d.out, d.width, d.channels)) return MI_BLUR_ERR_UNSUPPORTED;
-    return launch_tiled(d, f.tun ? *f.tun : tunables(), false, &f);
+    const Tunables &tn = f.tun ? *f.tun : tunables();
+    if (tiled_eligible(d.in, d.out, d.width, d.channels)) return launch_tiled(d, tn, false, &f);
+    // rows that are not a multiple of 16 bytes, buffers at odd addresses: the ragged form of the same tiles
+    if (tn.ragged && ragged_eligible(d.width, d.channels) && f.tail_ctr) return launch_tiled(d, tn, true, &f);
+    return MI_BLUR_ERR_UNSUPPORTED;
 }
 
 static int launch_stream(const LaunchDesc &d, const Tunables &tun)

@@ -31,7 +31,7 @@ int launch(const LaunchDesc &d);
 // batch_images; every block of batch b adds *waves_per_block (1) to one of count[kb .. kb+k-1], k = *counters_per_batch
 // (device, zeroed by the caller) after its stores have drained, so batch b is complete when those k sum to its blocks (geometry outputs:
 // a full batch has *tiles_per_batch blocks, the last one what is left of *total_blocks).
-// Aligned tiled shapes only (MI_BLUR_ERR_UNSUPPORTED otherwise).
+// Shapes of the tiled kernel, aligned or ragged, 1-4 channels (MI_BLUR_ERR_UNSUPPORTED otherwise; ragged rows need f.tail_ctr).
 // geometry_only: fill the geometry outputs for these knobs and return without launching (the caller decides from them
 // whether its counters can keep counting up).  tun: the knob set to use (nullptr = the current one); a caller that asks
 // for the geometry first passes the same copy to both calls.

@@ -319,7 +319,8 @@ void mi_blur_timed_coverage(mi_blur_ctx *ctx, uint64_t *launches, uint64_t *byte
  * the batches itself — blocks ordered in windows of 8 batches, in stream order — and every workgroup counts itself into its batch's counter once
  * its outputs are in memory.  The batch stays the unit of COMPLETION (mi_blur_resident_batches_done reads the
  * counters and returns how many leading batches have their outputs ready, without waiting for the dispatch, which
- * may still be running) without being the unit of DISPATCH.  n_images <= pool size (one contiguous run of the pool); aligned tiled shapes only
+ * may still be running) without being the unit of DISPATCH.  n_images <= pool size (one contiguous run of the pool); 1-4 channels, rows of
+ * at least 16 bytes — rows that are a multiple of 16 bytes take the aligned tiles, any other width their ragged form
  * (MI_BLUR_ERR_UNSUPPORTED otherwise).  `timed` is a bit set: 1 = the dispatch carries timestamp events like resident_run;
  * 2 = WATCH this pass: a one-wave kernel on a stream of its own follows the counters and keeps "leading batches complete" in
  * pinned host memory, so that mi_blur_resident_batches_done is a read of the caller's own memory (tens of ns, no HIP call)

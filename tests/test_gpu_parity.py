@@ -1337,8 +1337,9 @@ def test_fused_stream_parity_and_batch_flags(pkg, L, O, torch_cuda):
         ctx.resident_download(0, got.ctypes.data, batch)
         ctx.sync()
         assert np.array_equal(got, O.blur_batch(O.lcg_stream(batch, h, w, c), 1))
-    # ragged rows are not taken by the fused form
-    with pkg.Context(0, 17, 9, 3, 1, max_batch=1, n_slots=1) as ctx:
+    # rows shorter than one 16-byte chunk have no tile form at all, so no fused form either (longer ragged rows do: see
+    # test_fused_stream_ragged_rows)
+    with pkg.Context(0, 5, 9, 3, 1, max_batch=1, n_slots=1) as ctx:
         ctx.resident_alloc(4)
         assert L.mi_blur_resident_run_fused(ctx.h, 4, 2, 0) == pkg.ERR_UNSUPPORTED
 
@@ -1418,6 +1419,45 @@ def test_fused_stream_big_batches(pkg, L, O, torch_cuda):
         ctx.resident_run_fused(700, 300)
         ctx.sync()
         assert ctx.resident_batches_done() == 3
+
+
+def test_fused_stream_ragged_rows(pkg, L, O, torch_cuda):
+    """The fused stream on frames whose rows are not a multiple of 16 bytes (250x250x3, 1366-wide, odd little shapes): the ragged
+    form of the tile code with its stores — whole chunks and the 8/4/2/1-byte pieces of a row's last chunk — written through L2
+    like the aligned form's.  Every image equals the oracle, batches are counted exactly, short passes (static map) and long
+    ones (dynamic tail), 1-4 channels, both kernel sizes, repeated passes, a watched pass, the release-ordered count."""
+    rng = np.random.default_rng(404)
+    cases = [(250, 250, 3, 1, 300, 35), (61, 37, 3, 2, 120, 7), (30, 1366, 3, 1, 12, 5), (17, 33, 1, 1, 40, 40), (9, 17, 3, 2, 9, 2),
+             (64, 50, 3, 1, 9000, 35), (40, 30, 4, 2, 8500, 500), (33, 21, 2, 1, 64, 9)]
+    for case, (h, w, c, r, n, batch) in enumerate(cases):
+        assert (w * c) % 16 != 0
+        src = O.lcg_stream(n, h, w, c, first_index=case)
+        want = O.blur_batch(src, r)
+        nb = (n + batch - 1) // batch
+        with pkg.Context(0, w, h, c, r, max_batch=1, n_slots=1) as ctx:
+            ctx.resident_alloc(n)
+            ctx.resident_fill_synthetic(case)
+            for rep in range(3):
+                pkg.check(L.mi_blur_set_option(b"fused_release", 1 if rep == 2 else 0))
+                try:
+                    ctx.resident_run_fused(n, batch, watch=(rep == 1))
+                    assert L.mi_blur_last_kernel() == b"blur_fused_tail_kernel"
+                    ctx.sync()
+                finally:
+                    pkg.check(L.mi_blur_set_option(b"fused_release", 0))
+                assert ctx.resident_batches_done() == nb, (case, rep)
+                out = np.zeros_like(src)
+                ctx.resident_download(0, out.ctypes.data, n)
+                assert np.array_equal(out, want), (case, h, w, c, r, n, batch, rep)
+            # batches readable as soon as counted, on the long cases: poll, then peek the last image of the reported batches
+            if n >= 8000:
+                ctx.resident_run_fused(n, batch)
+                done = ctx.wait_batches(max(1, nb // 4), timeout_s=30.0)
+                last = min(done * batch, n) - 1
+                got = np.zeros((1, h, w, c), np.uint8)
+                ctx.resident_peek(last, got.ctypes.data, 1)
+                ctx.sync()
+                assert np.array_equal(got[0], want[last]), (case, done)
 
 
 def test_fused_stream_random_shapes(pkg, L, O, torch_cuda):

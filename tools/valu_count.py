@@ -17,7 +17,7 @@ def main():
         "3x3 tiled, rows/thread 8 (split-then-shift row pass: shipped)": "_ZN7mi_blur17blur_tiled_kernelILi3ELi1ELi8ELb1ELb0ELb0EEEvNS_11TiledParamsE",
         "3x3 tiled, rows/thread 8 (raw-window row pass: A/B form)": "_ZN7mi_blur19blur_tiled_x_kernelILi3ELi1ELi8ELi1EEEvNS_11TiledParamsE",
         "3x3 fused stream, rows/thread 8": "_ZN7mi_blur17blur_fused_kernelILi3ELi1ELi8EEEvNS_11TiledParamsENS_11FusedParamsE",
-        "3x3 fused stream with dynamic tail, rows/thread 8": "_ZN7mi_blur22blur_fused_tail_kernelILi3ELi1ELi8EEEvNS_11TiledParamsENS_11FusedParamsE",
+        "3x3 fused stream with dynamic tail, rows/thread 8": "_ZN7mi_blur22blur_fused_tail_kernelILi3ELi1ELi8ELb0EEEvNS_11TiledParamsENS_11FusedParamsE",
         "5x5 tiled, rows/thread 8 (raw-window row pass: shipped)": "_ZN7mi_blur17blur_tiled_kernelILi3ELi2ELi8ELb1ELb0ELb0EEEvNS_11TiledParamsE",
         "5x5 tiled, rows/thread 8 (split-then-shift row pass: round-1 form)": "_ZN7mi_blur19blur_tiled_x_kernelILi3ELi2ELi8ELi0EEEvNS_11TiledParamsE",
         "5x5 streaming variant": "_ZN7mi_blur18blur_stream_kernelILi3ELi2EEEvNS_12StreamParamsE",
