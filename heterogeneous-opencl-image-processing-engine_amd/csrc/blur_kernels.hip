@@ -1188,7 +1188,7 @@ static Tunables &tunables_storage()
         Tunables v{};                                    // everything 0 / off unless named here (rpg 0 / stream_bh 0 = choose per launch)
         v.stage_dma = 1; v.xcd_remap = 1; v.zero_copy = 1; v.ragged = 1;
         v.zero_copy_streams = 4; v.zero_copy_blocks = 24; v.stream_updown = 1; v.prefer_direct = 1; v.direct_bh = 8; v.fused_window = 8;
-        v.zero_copy_server = 1; v.staged_server = 1; v.zero_copy_workers = 48; v.zero_copy_idle_us = 300; v.zero_copy_budget = 256; v.zero_copy_tickets = 1;
+        v.zero_copy_server = 1; v.zero_copy_server_min_kb = 1280; v.staged_server = 1; v.zero_copy_workers = 48; v.zero_copy_idle_us = 300; v.zero_copy_budget = 256; v.zero_copy_tickets = 1;
         v.zero_copy_events = 1;
         v.fused_tail = 30; v.fused_tail_blocks = 25;
         v.resident_place_trials = 4;

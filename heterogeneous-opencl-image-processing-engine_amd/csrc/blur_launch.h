@@ -133,6 +133,7 @@ struct Tunables {
     int fused_tail_blocks; // ... by (100 + this) % as many extra workgroups as there are tail tiles (one ticket each; default 100)
     int zero_copy_server;  // zero-copy submits of aligned shapes go through the batch server (one long-lived dispatch per stream of
                            // batches, blur_server_kernel) instead of one launch per batch: 1 (default) | 0
+    int zero_copy_server_min_kb; // batch server: submits whose output is smaller than this many KiB take one launch each instead (default 1280)
     int staged_server;     // submits of PAGEABLE caller memory: 1 (default) = the batch server works on the slot's pinned staging buffers in
                            // place, 0 = DMA copy in, launch on device buffers, DMA copy out
     int zero_copy_workers; // batch server: worker workgroups (default 48: 40-64 measured best, profiles/r03_e2e_timeline.md)

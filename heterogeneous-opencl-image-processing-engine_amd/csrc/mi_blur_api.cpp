@@ -105,6 +105,7 @@ extern "C" int mi_blur_set_option(const char *key, int value)
     else if (!strcmp(key, "zero_copy_events")) t.zero_copy_events = value != 0;
     else if (!strcmp(key, "zero_copy_server")) t.zero_copy_server = value != 0;
     else if (!strcmp(key, "staged_server")) t.staged_server = value != 0;
+    else if (!strcmp(key, "zero_copy_server_min_kb")) { if (value < 0 || value > (1 << 20)) return MI_BLUR_ERR_INVALID; t.zero_copy_server_min_kb = value; }
     else if (!strcmp(key, "zero_copy_trace")) t.zero_copy_trace = value != 0;
     else if (!strcmp(key, "zero_copy_tickets")) t.zero_copy_tickets = value != 0;
     else if (!strcmp(key, "zero_copy_spin")) t.zero_copy_spin = value != 0;
@@ -770,7 +771,10 @@ static int submit_common(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_o
                 d.in = zin; d.out = zout; d.width = c->W; d.band_rows = band_rows; d.channels = c->C;
                 d.radius = c->R; d.n_images = n_images; d.y0 = y0; d.y1 = y1; d.variant = MI_BLUR_VARIANT_AUTO;
                 d.in_stride = (long long)in_stride; d.out_stride = (long long)out_stride;
-                if (tun.zero_copy_server) {
+                // small batches stay with one launch each: the server's hand-off (descriptor over the link, poller, completion
+                // word, the host's wait) costs ~26 us per batch against ~8 us for a launch — below ~1.3 MB each way the launch
+                // wins, by up to 3x for a single 256x256 frame (profiles/r03_e2e_shape_sweep.txt)
+                if (tun.zero_copy_server && out_bytes >= (size_t)tun.zero_copy_server_min_kb * 1024u) {
                     rc = zc_server_submit(c, s, d, tun);
                     if (rc == MI_BLUR_OK) {
                         s.zero_copy = true; s.busy = true;
@@ -823,6 +827,8 @@ static int submit_common(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_o
         // link — instead of a DMA copy each way around a launch (copies in both directions at once collapse to ~28 GB/s in
         // total on this platform, profiles/r01_pcie_probe.txt).  What stays is the host's own gather / scatter between the
         // caller's memory and the staging.
+        // (any batch size: for small batches too the server on the staging beats two DMA copies around a launch — a single
+        // 256x256 frame per submit: 78 k against 36 k img/s)
         if (tun.zero_copy && tun.zero_copy_server && tun.staged_server) {
             const uint8_t *zin = pinned_device_ptr(src);
             uint8_t *zout = pinned_device_ptr(s.out_staged ? s.h_out : host_out);

@@ -102,6 +102,9 @@ const char *mi_blur_last_kernel(void);
  *   "resident_place_trials" 4 (default): see mi_blur_resident_alloc
  *   "zero_copy_spin"    0 (default) = a wait for a batch of the server spins ~20 us, then sleeps in 20 us steps (the core is
  *                      free for the threads that build the next batch); 1 = spin + yield only
+ *   "zero_copy_server_min_kb"  1280 (default): in-place submits whose output is smaller than this many KiB take one launch each
+ *                       instead of the server — its hand-off costs ~26 us per batch against ~8 us for a launch (a single 256x256
+ *                       frame per submit: 126 k against 40 k img/s); 0 = always the server
  *   "staged_server"    1 (default) | 0: submits of PAGEABLE caller memory (the reference's malloc'd batch buffers) are gathered into
  *                       the slot's pinned staging and blurred there in place by the batch server (staging in -> staging out over the
  *                       link, 220 k img/s at batch 35 and 500) instead of a DMA copy each way around a launch (120-158 k).

@@ -57,6 +57,7 @@ def reset_opts(L):
     L.mi_blur_set_option(b"direct_bh", 8)
     L.mi_blur_set_option(b"zero_copy_server", 1)
     L.mi_blur_set_option(b"staged_server", 1)
+    L.mi_blur_set_option(b"zero_copy_server_min_kb", 1280)
     L.mi_blur_set_option(b"zero_copy_workers", 48)
     L.mi_blur_set_option(b"zero_copy_idle_us", 300)
     L.mi_blur_set_option(b"zero_copy_budget", 256)
@@ -64,6 +65,14 @@ def reset_opts(L):
     L.mi_blur_set_option(b"fused_tail", 30)
     L.mi_blur_set_option(b"fused_tail_blocks", 25)
     L.mi_blur_set_option(b"resident_place_trials", 4)
+
+
+@pytest.fixture
+def server_for_small_batches(L):
+    """These tests drive the batch server with small frames: switch off the rule that sends submits below 1.25 MiB to per-batch launches."""
+    L.mi_blur_set_option(b"zero_copy_server_min_kb", 0)
+    yield
+    L.mi_blur_set_option(b"zero_copy_server_min_kb", 1280)
 
 
 def want_batch(O, host, radius):
@@ -513,7 +522,43 @@ def test_zero_copy_capped_grid_and_streams(pkg, L, O, torch_cuda, radius):
             L.mi_blur_host_free(pi); L.mi_blur_host_free(po)
 
 
-def test_batch_server_mixed_pinned_and_pageable_submits(pkg, L, O, torch_cuda):
+def test_small_in_place_submits_take_one_launch_each(pkg, L, O, torch_cuda):
+    """In-place (pinned) submits below 1.25 MiB of output are not worth the server's hand-off (~26 us per batch against ~8 us for
+    a launch): they take one launch each, bigger ones the server, on the same context, in any order; same bytes either way."""
+    h, w, c, radius = 256, 256, 3, 1
+    host = O.lcg_stream(10, h, w, c, first_index=77)
+    want = O.blur_batch(host, radius)
+    isz = h * w * c
+    p_in, p_out = L.mi_blur_host_alloc(10 * isz), L.mi_blur_host_alloc(10 * isz)
+    C.memmove(p_in, host.ctypes.data, 10 * isz)
+    out = np.ctypeslib.as_array((C.c_uint8 * (10 * isz)).from_address(p_out)).reshape(10, h, w, c)
+    try:
+        with pkg.Context(0, w, h, c, radius, max_batch=10, n_slots=3) as ctx:
+            for n, server in ((1, False), (6, False), (7, True), (10, True), (2, False), (10, True), (1, False)):
+                out[:] = 0xEE
+                ctx.submit(p_in, p_out, n)
+                ctx.sync()
+                assert (L.mi_blur_last_kernel() == b"blur_server_kernel") == server, (n, L.mi_blur_last_kernel())
+                assert np.array_equal(out[:n], want[:n]) and bool((out[n:] == 0xEE).all()), n
+            assert L.mi_blur_zero_copy_launches(ctx.h) == 7            # in place every time, whichever form
+            # both forms in flight at once on rotating slots
+            outs = [L.mi_blur_host_alloc(10 * isz) for _ in range(3)]
+            sizes = [1, 10, 3, 8, 2, 9, 10, 1, 7]
+            for i, n in enumerate(sizes):
+                if i >= 3:
+                    ctx.wait_oldest()
+                    m = sizes[i - 3]
+                    got = np.ctypeslib.as_array((C.c_uint8 * (m * isz)).from_address(outs[i % 3])).reshape(m, h, w, c)
+                    assert np.array_equal(got, want[:m]), i - 3
+                ctx.submit(p_in, outs[i % 3], n)
+            ctx.sync()
+            for o in outs:
+                L.mi_blur_host_free(o)
+    finally:
+        L.mi_blur_host_free(p_in); L.mi_blur_host_free(p_out)
+
+
+def test_batch_server_mixed_pinned_and_pageable_submits(pkg, L, O, torch_cuda, server_for_small_batches):
     """One context, one server: submits whose buffers are pinned (blurred in place), pageable (gathered into the slot's pinned
     staging, blurred there, scattered back when the slot is harvested) and half-and-half (pinned in / pageable out and the
     reverse), interleaved at random with random batch sizes; every batch verified and poisoned before its buffers are reused."""
@@ -556,7 +601,7 @@ def test_batch_server_mixed_pinned_and_pageable_submits(pkg, L, O, torch_cuda):
 
 
 @pytest.mark.parametrize("base,budget", [(40, 256), (40, 7), (3, 256), (100, 5)])
-def test_batch_server_number_wrap(pkg, L, O, torch_cuda, base, budget):
+def test_batch_server_number_wrap(pkg, L, O, torch_cuda, base, budget, server_for_small_batches):
     """The server numbers batches and tiles in 32 bits through the life of a context; a continuous batch-35 stream of 256x256
     frames uses up the tile numbers in ~80 minutes.  "zero_copy_debug_base" starts a new server `base` batches (7*base tiles)
     short of 2^32, so both counters wrap inside this test — at different batches, with the server rolling over (budget) before,
@@ -609,7 +654,7 @@ def test_batch_server_number_wrap(pkg, L, O, torch_cuda, base, budget):
 
 
 @pytest.mark.parametrize("radius", [1, 2])
-def test_zero_copy_batch_server(pkg, L, O, torch_cuda, radius):
+def test_zero_copy_batch_server(pkg, L, O, torch_cuda, radius, server_for_small_batches):
     """The default path of pinned host-to-host submits: ONE long-lived dispatch (blur_server_kernel) takes batch after batch
     from a descriptor ring, tiles handed out by a ticket counter that runs through the batches, completion per batch
     signalled into host memory.  Bit-exact vs the oracle for: a back-to-back stream on rotating buffers; a producer slower
