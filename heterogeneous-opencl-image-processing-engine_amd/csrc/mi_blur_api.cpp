@@ -20,6 +20,9 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <deque>
+#include <functional>
+#include <condition_variable>
 #include <thread>
 #include <vector>
 
@@ -229,9 +232,53 @@ struct ZcServer {
     int fixed_share = 0;                                 // A/B: "zero_copy_tickets" 0
 };
 
+// The CPU device's queue: submits run one after another on ONE long-lived thread per context (each of them spreads over the
+// worker pool inside cpu_blur_batch) — a thread per submit cost ~60 us, most of a small batch's time.
 struct CpuJob {
-    std::thread th;
+    std::function<void()> work;
     double ms = 0.0;
+    bool done = false;
+};
+struct CpuWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    std::deque<CpuJob *> q;
+    bool stop = false;
+    void loop()
+    {
+        for (;;) {
+            CpuJob *j = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv_work.wait(lk, [&] { return stop || !q.empty(); });
+                if (q.empty()) return;                   // stop, nothing left
+                j = q.front(); q.pop_front();
+            }
+            const auto t0 = std::chrono::steady_clock::now();
+            j->work();
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            { std::lock_guard<std::mutex> lk(m); j->ms = ms; j->done = true; }
+            cv_done.notify_all();
+        }
+    }
+    void push(CpuJob *j)
+    {
+        { std::lock_guard<std::mutex> lk(m); q.push_back(j); }
+        if (!th.joinable()) th = std::thread([this] { loop(); });
+        cv_work.notify_one();
+    }
+    void wait(CpuJob *j)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return j->done; });
+    }
+    ~CpuWorker()
+    {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv_work.notify_all();
+        if (th.joinable()) th.join();
+    }
 };
 
 }  // namespace
@@ -274,6 +321,7 @@ struct mi_blur_ctx {
     int place_kept = 0;
     // CPU device
     std::vector<CpuJob *> cpu_jobs;
+    CpuWorker *cpu_worker = nullptr;
     bool is_cpu() const { return device == MI_BLUR_DEVICE_CPU; }
 };
 
@@ -561,7 +609,7 @@ extern "C" int mi_blur_sync(mi_blur_ctx *c, mi_blur_timing *timing)
     if (!c) return MI_BLUR_ERR_INVALID;
     if (c->is_cpu()) {
         for (CpuJob *j : c->cpu_jobs) {
-            j->th.join();
+            c->cpu_worker->wait(j);
             c->tm.kernel_ms += j->ms;
             delete j;
         }
@@ -610,7 +658,8 @@ extern "C" void mi_blur_timed_coverage(mi_blur_ctx *c, uint64_t *launches, uint6
 extern "C" void mi_blur_destroy(mi_blur_ctx *c)
 {
     if (!c) return;
-    for (CpuJob *j : c->cpu_jobs) { j->th.join(); delete j; }
+    for (CpuJob *j : c->cpu_jobs) { c->cpu_worker->wait(j); delete j; }
+    delete c->cpu_worker;
     if (!c->is_cpu()) {
         (void)hipSetDevice(c->device);
         for (auto &s : c->slots) { if (s.stream) (void)hipStreamSynchronize(s.stream); }
@@ -736,11 +785,9 @@ static int submit_common(mi_blur_ctx *c, const uint8_t *host_in, uint8_t *host_o
         CpuJob *j = new (std::nothrow) CpuJob;
         if (!j) return MI_BLUR_ERR_NOMEM;
         const int W = c->W, C = c->C, R = c->R, nt = c->n_threads;
-        j->th = std::thread([=]() {
-            const auto t0 = std::chrono::steady_clock::now();
-            cpu_blur_batch(host_in, host_out, W, band_rows, C, R, n_images, y0, y1, nt, in_stride, out_stride);
-            j->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        });
+        j->work = [=]() { cpu_blur_batch(host_in, host_out, W, band_rows, C, R, n_images, y0, y1, nt, in_stride, out_stride); };
+        if (!c->cpu_worker) { c->cpu_worker = new (std::nothrow) CpuWorker; if (!c->cpu_worker) { delete j; return MI_BLUR_ERR_NOMEM; } }
+        c->cpu_worker->push(j);
         c->cpu_jobs.push_back(j);
     } else {
         HIP_TRY(hipSetDevice(c->device));
@@ -927,14 +974,14 @@ extern "C" int mi_blur_submit_planar(mi_blur_ctx *c, const uint8_t *host_planar_
         CpuJob *j = new (std::nothrow) CpuJob;
         if (!j) return MI_BLUR_ERR_NOMEM;
         const int W = c->W, H = c->H, C = c->C, R = c->R, nt = c->n_threads;
-        j->th = std::thread([=]() {
-            const auto t0 = std::chrono::steady_clock::now();
+        j->work = [=]() {
             std::vector<uint8_t> a(bytes), b(planar_out ? bytes : 0);
             cpu_repack(host_planar_in, a.data(), W, H, C, n_images, true, nt);
             cpu_blur_batch(a.data(), planar_out ? b.data() : host_out, W, H, C, R, n_images, 0, H, nt);
             if (planar_out) cpu_repack(b.data(), host_out, W, H, C, n_images, false, nt);
-            j->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        });
+        };
+        if (!c->cpu_worker) { c->cpu_worker = new (std::nothrow) CpuWorker; if (!c->cpu_worker) { delete j; return MI_BLUR_ERR_NOMEM; } }
+        c->cpu_worker->push(j);
         c->cpu_jobs.push_back(j);
     } else {
         HIP_TRY(hipSetDevice(c->device));
@@ -991,7 +1038,7 @@ extern "C" int mi_blur_wait_oldest(mi_blur_ctx *c)
     if (c->is_cpu()) {
         if (c->cpu_jobs.empty()) return MI_BLUR_OK;
         CpuJob *j = c->cpu_jobs.front();
-        j->th.join();
+        c->cpu_worker->wait(j);
         c->tm.kernel_ms += j->ms;
         delete j;
         c->cpu_jobs.erase(c->cpu_jobs.begin());
