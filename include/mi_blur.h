@@ -183,7 +183,8 @@ typedef struct mi_blur_timing {      /* cumulative since create / last reset; mi
  * max_batch: largest n_images of one submit.  n_slots: submits in flight (>=1).  Staged submits: 2-3 lets H2D(n+1),
  * kernel(n) and D2H(n-1) overlap.  In-place (pinned) submits through the batch server: a deeper queue costs the link
  * nothing and keeps the GPU fed while the host builds the next batch — the hosts use 4 (3 in split_image_blur).  Each
- * slot owns a pinned in/out pair, a device in/out pair and one stream. */
+ * slot owns one stream and — made by the first submit that needs them, so never for a context whose submits are all in
+ * place — a pinned in/out staging pair and a device in/out pair of max_batch images each. */
 int mi_blur_create(mi_blur_ctx **out_ctx, int device, int width, int height, int channels,
                    int radius, int max_batch, int n_slots, int n_threads);
 void mi_blur_destroy(mi_blur_ctx *ctx);
