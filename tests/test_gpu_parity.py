@@ -522,6 +522,40 @@ def test_zero_copy_capped_grid_and_streams(pkg, L, O, torch_cuda, radius):
             L.mi_blur_host_free(pi); L.mi_blur_host_free(po)
 
 
+def test_batches_past_2_31_bytes(pkg, L, O, torch_cuda):
+    """Eleven 8192x8192x3 frames in ONE submit — 2.2 GB each way, past 2^31 bytes — in place through the batch server and as one
+    launch over a resident pool: every output frame carries the reference kernel's hash of that frame (tests/golden; the
+    reference indexes with int, gaussian_kernel.cl:60, and would not get here).  tools/big_batch_check.py runs the other forms."""
+    import json
+    gold = json.load(open(os.path.join(pkg.ROOT, "tests", "golden", "blur_golden.json")))
+    W = H = 8192; c = 3; n = 11
+    isz = W * H * c
+    want = "d283787bcc5b6dfd"
+    assert any(want in json.dumps(v) for v in gold.values())            # the 8192^2 k3 entry
+    p_in, p_out = L.mi_blur_host_alloc(n * isz), L.mi_blur_host_alloc(n * isz)
+    assert p_in and p_out
+    try:
+        L.mi_blur_fill_synthetic(p_in, W, H, c, 0, 1, 8)
+        for i in range(1, n):
+            C.memmove(p_in + i * isz, p_in, isz)
+        C.memset(p_out, 0, n * isz)
+        with pkg.Context(0, W, H, c, 1, max_batch=n, n_slots=1) as ctx:
+            ctx.submit(p_in, p_out, n)
+            ctx.sync()
+            assert L.mi_blur_last_kernel() == b"blur_server_kernel"
+            assert [f"{L.mi_blur_fnv1a64(p_out + i * isz, isz):016x}" for i in range(n)] == [want] * n
+        C.memset(p_out, 0, n * isz)
+        with pkg.Context(0, W, H, c, 1, max_batch=1, n_slots=1) as ctx:
+            ctx.resident_alloc(n)
+            ctx.resident_upload(0, p_in, n)
+            ctx.resident_run(n, n)
+            ctx.sync()
+            ctx.resident_download(0, p_out, n)
+            assert [f"{L.mi_blur_fnv1a64(p_out + i * isz, isz):016x}" for i in range(n)] == [want] * n
+    finally:
+        L.mi_blur_host_free(p_in); L.mi_blur_host_free(p_out)
+
+
 def test_small_in_place_submits_take_one_launch_each(pkg, L, O, torch_cuda):
     """In-place (pinned) submits below 1.25 MiB of output are not worth the server's hand-off (~26 us per batch against ~8 us for
     a launch): they take one launch each, bigger ones the server, on the same context, in any order; same bytes either way."""
