@@ -522,6 +522,29 @@ def test_zero_copy_capped_grid_and_streams(pkg, L, O, torch_cuda, radius):
             L.mi_blur_host_free(pi); L.mi_blur_host_free(po)
 
 
+@pytest.mark.parametrize("shape", [(1, 100000, 3), (100000, 1, 3), (3, 65536, 4), (70000, 16, 1), (2, 1000003, 1), (40000, 17, 3),
+                                   (65537, 48, 2), (5, 262144, 3)])
+def test_extreme_aspect_ratios(pkg, L, O, torch_cuda, shape):
+    """One-row, one-column, million-pixel-wide and 70000-row frames (the reference kernel's NDRange takes any W x H): through the
+    kernel-level entry and through a context with pageable buffers (staging + batch server), 3x3 and 5x5."""
+    torch = torch_cuda
+    h, w, c = shape
+    img = O.lcg_image(h, w, c)
+    for r in (1, 2):
+        want = O.blur(img, r)
+        d_in = torch.from_numpy(img.reshape(-1)).cuda()
+        d_out = torch.zeros_like(d_in)
+        pkg.check(L.mi_blur_enqueue(d_in.data_ptr(), d_out.data_ptr(), w, h, c, r, 1, None))
+        torch.cuda.synchronize()
+        assert np.array_equal(d_out.cpu().numpy().reshape(h, w, c), want), (shape, r, L.mi_blur_last_kernel())
+        stack = np.stack([img, np.ascontiguousarray(img[::-1]), img])
+        out = np.zeros_like(stack)
+        with pkg.Context(0, w, h, c, r, max_batch=3, n_slots=2) as ctx:
+            ctx.submit(stack.ctypes.data, out.ctypes.data, 3)
+            ctx.sync()
+        assert np.array_equal(out, O.blur_batch(stack, r)), (shape, r, "context")
+
+
 def test_batches_past_2_31_bytes(pkg, L, O, torch_cuda):
     """Eleven 8192x8192x3 frames in ONE submit — 2.2 GB each way, past 2^31 bytes — in place through the batch server and as one
     launch over a resident pool: every output frame carries the reference kernel's hash of that frame (tests/golden; the
