@@ -545,6 +545,59 @@ def test_extreme_aspect_ratios(pkg, L, O, torch_cuda, shape):
         assert np.array_equal(out, O.blur_batch(stack, r)), (shape, r, "context")
 
 
+def test_contexts_driven_from_different_threads(pkg, L, O, torch_cuda):
+    """A context is single-threaded; DIFFERENT contexts may be driven from different host threads at once (the 8-GPU hosts do,
+    one feeder thread per GPU).  Four threads, each with its own context on the one device — two with pinned buffers, two with
+    pageable ones (shared gather/scatter pool, one batch server each) — stream at the same time; every batch of every thread is
+    verified.  ctypes releases the GIL inside the library, so the threads really overlap."""
+    import threading
+    h, w, c, n, radius = 128, 256, 3, 16, 1                      # 1.5 MiB per batch: the server's side of the small-submit rule
+    host = O.lcg_stream(n, h, w, c, first_index=500)
+    want = O.blur_batch(host, radius)
+    nbytes = host.nbytes
+    errors = []
+
+    def worker(tid, pageable):
+        try:
+            if pageable:
+                bufs = [(host.copy(), np.zeros_like(host)) for _ in range(3)]
+                ptrs = [(a.ctypes.data, b.ctypes.data) for a, b in bufs]
+                view = lambda k: bufs[k][1]
+            else:
+                ptrs = [(L.mi_blur_host_alloc(nbytes), L.mi_blur_host_alloc(nbytes)) for _ in range(3)]
+                for pi, _po in ptrs:
+                    C.memmove(pi, host.ctypes.data, nbytes)
+                view = lambda k: np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(ptrs[k][1])).reshape(host.shape)
+            rng = np.random.default_rng(tid)
+            sizes = [n] * 3
+            with pkg.Context(0, w, h, c, radius, max_batch=n, n_slots=3) as ctx:
+                for i in range(120):
+                    k = i % 3
+                    if i >= 3:
+                        ctx.wait_oldest()
+                        got = view(k)
+                        if not np.array_equal(got[:sizes[k]], want[:sizes[k]]):
+                            errors.append((tid, i - 3, "mismatch"))
+                            return
+                        got[:] = 0
+                    sizes[k] = int(rng.integers(n // 2, n + 1))
+                    ctx.submit(ptrs[k][0], ptrs[k][1], sizes[k])
+                ctx.sync()
+            if not pageable:
+                for pi, po in ptrs:
+                    L.mi_blur_host_free(pi); L.mi_blur_host_free(po)
+        except Exception as e:                                   # noqa: BLE001 - reported below
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t, t % 2 == 1)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a feeder thread is stuck"
+    assert not errors, errors
+
+
 def test_batches_past_2_31_bytes(pkg, L, O, torch_cuda):
     """Eleven 8192x8192x3 frames in ONE submit — 2.2 GB each way, past 2^31 bytes — in place through the batch server and as one
     launch over a resident pool: every output frame carries the reference kernel's hash of that frame (tests/golden; the
