@@ -1190,7 +1190,7 @@ static Tunables &tunables_storage()
         v.zero_copy_streams = 4; v.zero_copy_blocks = 24; v.stream_updown = 1; v.prefer_direct = 1; v.direct_bh = 8; v.fused_window = 8;
         v.zero_copy_server = 1; v.zero_copy_server_min_kb = 1280; v.staged_server = 1; v.zero_copy_workers = 48; v.zero_copy_idle_us = 300; v.zero_copy_budget = 256; v.zero_copy_tickets = 1;
         v.zero_copy_events = 1;
-        v.fused_tail = 30; v.fused_tail_blocks = 25;
+        v.fused_tail = 30; v.fused_tail_blocks = 25; v.fused_adds_per_word = 32;
         v.resident_place_trials = 4;
         if (const char *e = getenv("MI_BLUR_PLACE_TRIALS")) { const int r = atoi(e); if (r >= 0 && r <= 8) v.resident_place_trials = r; }
         if (const char *e = getenv("MI_BLUR_STAGED_SERVER")) v.staged_server = atoi(e) != 0;
@@ -1458,7 +1458,7 @@ static int launch_tiled(const LaunchDesc &d, const Tunables &tun, bool ragged = 
         f.tiles_per_batch = (unsigned)tpb;
         // counters per batch: at most ~64 adds per word and pass, within what the caller's counter array holds
         unsigned k = 8;
-        while (k < 256u && tpb > 64ll * k) k *= 2;
+        while (k < 256u && tpb > (long long)std::max(4, tun.fused_adds_per_word) * k) k *= 2;
         const long long nbatches = ((long long)d.n_images + fused->batch_images - 1) / fused->batch_images;
         while (k > 8u && fused->count_words > 0 && (long long)k * nbatches > fused->count_words) k /= 2;
         f.kcount = k;

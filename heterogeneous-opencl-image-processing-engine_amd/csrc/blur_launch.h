@@ -130,6 +130,7 @@ struct Tunables {
     int debug_xcd_times; // diagnostics: the tiled kernel's workgroups leave start/end times per XCD (mi_blur_debug_xcd_times)
     int fused_window;    // fused stream: batches per window of its blockIdx -> tile map (8: one whole batch per XCD per window)
     int fused_tail;      // fused stream: per mille of a pass's tiles that are handed out dynamically at the end (0 = none)
+    int fused_adds_per_word; // fused stream: a batch gets as many completion counters (8 .. 256) as keep the adds per counter and pass under this
     int fused_tail_blocks; // ... by (100 + this) % as many extra workgroups as there are tail tiles (one ticket each; default 100)
     int zero_copy_server;  // zero-copy submits of aligned shapes go through the batch server (one long-lived dispatch per stream of
                            // batches, blur_server_kernel) instead of one launch per batch: 1 (default) | 0

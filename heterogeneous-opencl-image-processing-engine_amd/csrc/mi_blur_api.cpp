@@ -101,6 +101,7 @@ extern "C" int mi_blur_set_option(const char *key, int value)
     else if (!strcmp(key, "zero_copy_blocks")) { if (value < 0 || value > (1 << 20)) return MI_BLUR_ERR_INVALID; t.zero_copy_blocks = value; }
     else if (!strcmp(key, "prefer_direct")) { if (value < 0 || value > 2) return MI_BLUR_ERR_INVALID; t.prefer_direct = value; }
     else if (!strcmp(key, "direct_bh")) { if (value != 4 && value != 8 && value != 12 && value != 16) return MI_BLUR_ERR_INVALID; t.direct_bh = value; }
+    else if (!strcmp(key, "fused_adds_per_word")) { if (value < 4 || value > 4096) return MI_BLUR_ERR_INVALID; t.fused_adds_per_word = value; }
     else if (!strcmp(key, "fused_tail_blocks")) { if (value < 10 || value > 800) return MI_BLUR_ERR_INVALID; t.fused_tail_blocks = value; }
     else if (!strcmp(key, "fused_tail")) { if (value < 0 || value > 500) return MI_BLUR_ERR_INVALID; t.fused_tail = value; }
     else if (!strcmp(key, "fused_window")) { if (value < 1 || value > 4096) return MI_BLUR_ERR_INVALID; t.fused_window = value; }
@@ -1266,6 +1267,10 @@ extern "C" int mi_blur_resident_run(mi_blur_ctx *c, int n_images, int batch, int
 
 // The same pass as ONE dispatch (blur_fused_kernel): the GPU walks the batches in order and raises a host-visible
 // flag per finished batch, so the batch stays the unit of completion without being the unit of dispatch.
+// Words of the per-batch completion counters for a pool of `cap` images: 8 per batch at the smallest batch (one image), plus room
+// for a few batches of thousands of tiles to spread over up to 256 words each (two 8192x8192 frames are two batches of 3200 tiles)
+static size_t fused_words(int cap) { return 8 * (size_t)cap + 16384; }
+
 extern "C" int mi_blur_resident_run_fused(mi_blur_ctx *c, int n_images, int batch, int timed)
 {
     if (!c || n_images <= 0 || batch <= 0) return MI_BLUR_ERR_INVALID;
@@ -1281,10 +1286,10 @@ extern "C" int mi_blur_resident_run_fused(mi_blur_ctx *c, int n_images, int batc
         c->fused_cap = 0;
         const int cap = std::max(nb, c->pool_images);      // enough for any batch size on this pool: never reallocated
         // (+16 words: the ticket counter of a pass's dynamic tail lives behind the batch counters; it is zero between passes)
-        HIP_TRY(hipMalloc((void **)&c->fused_count, sizeof(unsigned) * (8 * (size_t)cap + 16)));
-        HIP_TRY(hipMemset(c->fused_count + 8 * (size_t)cap, 0, sizeof(unsigned) * 16));
+        HIP_TRY(hipMalloc((void **)&c->fused_count, sizeof(unsigned) * (fused_words(cap) + 16)));
+        HIP_TRY(hipMemset(c->fused_count + fused_words(cap), 0, sizeof(unsigned) * 16));
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipHostMalloc((void **)&c->fused_host, sizeof(unsigned) * 8 * (size_t)cap, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&c->fused_host, sizeof(unsigned) * fused_words(cap), hipHostMallocDefault));
         c->fused_cap = cap;
         c->fused_passes = 0;
     }
@@ -1292,7 +1297,7 @@ extern "C" int mi_blur_resident_run_fused(mi_blur_ctx *c, int n_images, int batc
         HIP_TRY(hipStreamCreateWithFlags(&c->fused_poll, hipStreamNonBlocking));
         // the first device-to-host copy of this size class sets up the copy engine's queue (~8 ms): pay it here, not
         // in the first poll
-        HIP_TRY(hipMemcpyAsync(c->fused_host, c->fused_count, sizeof(unsigned) * 8 * (size_t)c->fused_cap, hipMemcpyDeviceToHost, c->fused_poll));
+        HIP_TRY(hipMemcpyAsync(c->fused_host, c->fused_count, sizeof(unsigned) * fused_words(c->fused_cap), hipMemcpyDeviceToHost, c->fused_poll));
         HIP_TRY(hipStreamSynchronize(c->fused_poll));
     }
     if (c->cursor + n_images > c->pool_images) c->cursor = 0;
@@ -1306,7 +1311,7 @@ extern "C" int mi_blur_resident_run_fused(mi_blur_ctx *c, int n_images, int batc
     // knobs, ask for the geometry first, launch with the same copy.
     const Tunables tun = tunables();
     unsigned tpb = 0, wpb = 0, blocks = 0, kcnt = 8;
-    FusedDesc f{c->fused_count, batch, &tpb, &wpb, &blocks, &tun, true, c->fused_count + 8 * (size_t)c->fused_cap, 8ll * c->fused_cap, &kcnt};
+    FusedDesc f{c->fused_count, batch, &tpb, &wpb, &blocks, &tun, true, c->fused_count + fused_words(c->fused_cap), (long long)fused_words(c->fused_cap), &kcnt};
     int rc = launch_fused(d, f);
     if (rc) return rc;
     // Repeated passes of the same shape AND geometry do not zero the counters (that would be one more dispatch per
