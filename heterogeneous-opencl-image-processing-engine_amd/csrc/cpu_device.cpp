@@ -43,16 +43,20 @@ public:
         {
             std::lock_guard<std::mutex> lk(m_);
             fn_ = &fn; active_ = n_workers - 1; pending_ = n_workers - 1; gen_++;
+            pending_hint_.store(pending_, std::memory_order_release);
+            gen_hint_.store(gen_, std::memory_order_release);
         }
         cv_.notify_all();
         fn(0);
+        // the helpers finish within microseconds of the caller: look before sleeping
+        for (int i = 0; i < SPIN && pending_hint_.load(std::memory_order_acquire) != 0; i++) cpu_relax();
         std::unique_lock<std::mutex> lk(m_);
         done_.wait(lk, [this] { return pending_ == 0; });
         fn_ = nullptr;
     }
     ~Pool()
     {
-        { std::lock_guard<std::mutex> lk(m_); stop_ = true; gen_++; }
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; gen_++; gen_hint_.store(gen_, std::memory_order_release); }
         cv_.notify_all();
         for (auto &t : th_) t.join();
     }
@@ -70,6 +74,9 @@ private:
         unsigned long long seen = 0;
         for (;;) {
             const std::function<void(int)> *fn = nullptr;
+            // a stream of batches wakes the pool every ~100 us: a worker that has just finished spins that long for the next
+            // generation before it goes to sleep on the condition variable (a sleeping worker costs the batch ~30-50 us)
+            for (int i = 0; i < SPIN && gen_hint_.load(std::memory_order_acquire) == seen; i++) cpu_relax();
             {
                 std::unique_lock<std::mutex> lk(m_);
                 cv_.wait(lk, [&] { return gen_ != seen; });
@@ -80,10 +87,20 @@ private:
             if (fn) {
                 (*fn)(id);
                 std::lock_guard<std::mutex> lk(m_);
+                pending_hint_.store(pending_ - 1, std::memory_order_release);
                 if (--pending_ == 0) done_.notify_one();
             }
         }
     }
+    static constexpr int SPIN = 20000;                    // ~100-200 us of pause instructions
+    static void cpu_relax()
+    {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+    }
+    std::atomic<unsigned long long> gen_hint_{0};
+    std::atomic<int> pending_hint_{0};
     std::mutex call_m_, m_;
     std::condition_variable cv_, done_;
     std::vector<std::thread> th_;
@@ -139,8 +156,10 @@ void cpu_blur_batch(const uint8_t *in, uint8_t *out, int W, int band_rows, int C
     if (out_stride == 0) out_stride = (size_t)W * C * (y1 - y0);
     const int rows = y1 - y0;
     // work items: (image, row slice)
+    // enough items for the threads to end together: a batch of 35 images on 16 threads is three rounds of whole images with the
+    // last one half empty; cut into row slices (of at least 16 rows) until there are ~4 items per thread
     int slices = 1;
-    if (n_images < n_threads) slices = std::min(rows, (n_threads + n_images - 1) / n_images);
+    if (n_images < 4 * n_threads) slices = std::max(1, std::min(std::max(1, rows / 16), (4 * n_threads + n_images - 1) / n_images));
     const long long items = (long long)n_images * slices;
     std::atomic<long long> next{0};
     auto worker = [&]() {
