@@ -12,6 +12,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <functional>
@@ -40,6 +42,13 @@ public:
         if (n_workers <= 1) { fn(0); return; }
         std::lock_guard<std::mutex> call(call_m_);
         grow(n_workers - 1);
+        // Spinning pays only while batches follow each other closely (a stream: one every ~100 us); a caller that does something
+        // long between two uses of the pool — builds a batch on one thread, say — should find the helpers asleep, not burning
+        // the cores (and the cgroup's CPU quota) it is working on.  The gap since the previous use decides.
+        const auto now = std::chrono::steady_clock::now();
+        const double gap_us = std::chrono::duration<double, std::micro>(now - last_done_).count();
+        static const int spin_max = [] { const char *e = getenv("MI_BLUR_POOL_SPIN"); const int v = e ? atoi(e) : -1; return v >= 0 ? v : SPIN; }();
+        spin_budget_.store(gap_us < 250.0 ? spin_max : 0, std::memory_order_relaxed);
         {
             std::lock_guard<std::mutex> lk(m_);
             fn_ = &fn; active_ = n_workers - 1; pending_ = n_workers - 1; gen_++;
@@ -49,10 +58,11 @@ public:
         cv_.notify_all();
         fn(0);
         // the helpers finish within microseconds of the caller: look before sleeping
-        for (int i = 0; i < SPIN && pending_hint_.load(std::memory_order_acquire) != 0; i++) cpu_relax();
+        for (int i = 0; i < 4000 && pending_hint_.load(std::memory_order_acquire) != 0; i++) cpu_relax();
         std::unique_lock<std::mutex> lk(m_);
         done_.wait(lk, [this] { return pending_ == 0; });
         fn_ = nullptr;
+        last_done_ = std::chrono::steady_clock::now();
     }
     ~Pool()
     {
@@ -76,7 +86,7 @@ private:
             const std::function<void(int)> *fn = nullptr;
             // a stream of batches wakes the pool every ~100 us: a worker that has just finished spins that long for the next
             // generation before it goes to sleep on the condition variable (a sleeping worker costs the batch ~30-50 us)
-            for (int i = 0; i < SPIN && gen_hint_.load(std::memory_order_acquire) == seen; i++) cpu_relax();
+            for (int i = 0, n = spin_budget_.load(std::memory_order_relaxed); i < n && gen_hint_.load(std::memory_order_acquire) == seen; i++) cpu_relax();
             {
                 std::unique_lock<std::mutex> lk(m_);
                 cv_.wait(lk, [&] { return gen_ != seen; });
@@ -99,6 +109,8 @@ private:
         __builtin_ia32_pause();
 #endif
     }
+    std::atomic<int> spin_budget_{0};
+    std::chrono::steady_clock::time_point last_done_{};
     std::atomic<unsigned long long> gen_hint_{0};
     std::atomic<int> pending_hint_{0};
     std::mutex call_m_, m_;
@@ -158,8 +170,10 @@ void cpu_blur_batch(const uint8_t *in, uint8_t *out, int W, int band_rows, int C
     // work items: (image, row slice)
     // enough items for the threads to end together: a batch of 35 images on 16 threads is three rounds of whole images with the
     // last one half empty; cut into row slices (of at least 16 rows) until there are ~4 items per thread
+    static const int per_thread = [] { const char *e = getenv("MI_BLUR_POOL_ITEMS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? v : 4; }();
     int slices = 1;
-    if (n_images < 4 * n_threads) slices = std::max(1, std::min(std::max(1, rows / 16), (4 * n_threads + n_images - 1) / n_images));
+    if (n_images < per_thread * n_threads)
+        slices = std::max(1, std::min(std::max(1, rows / 16), (per_thread * n_threads + n_images - 1) / n_images));
     const long long items = (long long)n_images * slices;
     std::atomic<long long> next{0};
     auto worker = [&]() {
