@@ -52,4 +52,7 @@ for w in a1 hd5; do
     pmc ${w}_tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum -- $extra
 done
 fi
+# the per-dispatch traces are large (the whole round would not fit gpurun's 64 MiB return) and nothing downstream reads them:
+# summarize_profiles.py works from the *_kernel_stats.csv and *_counter_collection.csv files
+find $OUT -name "*_kernel_trace.csv" -delete
 echo "done"; du -sh $OUT
