@@ -47,7 +47,11 @@ public:
         // the cores (and the cgroup's CPU quota) it is working on.  The gap since the previous use decides.
         const auto now = std::chrono::steady_clock::now();
         const double gap_us = std::chrono::duration<double, std::micro>(now - last_done_).count();
-        static const int spin_max = [] { const char *e = getenv("MI_BLUR_POOL_SPIN"); const int v = e ? atoi(e) : -1; return v >= 0 ? v : SPIN; }();
+        // OFF by default (MI_BLUR_POOL_SPIN=<pause count> turns it on): measured, it is worth +30 % to a caller that does nothing
+        // but feed the pool on an idle 8-vCPU VM, nothing on the 256-thread GPU hosts (a sleeping worker is woken fast enough
+        // there: 71-95 us per 35-image batch on 16 threads either way), and it costs 4x inside the hosts on the small VM, where
+        // the spinners take the cores the batch-building threads need
+        static const int spin_max = [] { const char *e = getenv("MI_BLUR_POOL_SPIN"); const int v = e ? atoi(e) : -1; return v >= 0 ? v : 0; }();
         spin_budget_.store(gap_us < 250.0 ? spin_max : 0, std::memory_order_relaxed);
         {
             std::lock_guard<std::mutex> lk(m_);
