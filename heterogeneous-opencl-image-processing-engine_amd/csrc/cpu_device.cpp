@@ -106,7 +106,6 @@ private:
             }
         }
     }
-    static constexpr int SPIN = 20000;                    // ~100-200 us of pause instructions
     static void cpu_relax()
     {
 #if defined(__x86_64__) || defined(__i386__)
