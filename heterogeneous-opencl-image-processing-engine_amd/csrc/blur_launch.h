@@ -69,8 +69,8 @@ int launch_halo_pull(const uint8_t *top_src, uint8_t *top_dst, const uint8_t *bo
 // ----------------------------------------------------------------------------------------------------------------
 constexpr unsigned ZC_RING = 64;
 constexpr unsigned ZC_PARAM_WORDS = 32;
-constexpr unsigned ZC_TRACE_BATCHES = 512;
-constexpr unsigned long long ZC_HARD_TICKS = 1000000000ull;   // 10 s of the 100 MHz device clock: no wait inside a server outlasts this   // diagnostics: the trace keeps the stamps of the last this-many batches
+constexpr unsigned ZC_TRACE_BATCHES = 512;                    // diagnostics: the trace keeps the stamps of a context's first this-many batches
+constexpr unsigned long long ZC_HARD_TICKS = 1000000000ull;   // 10 s of the 100 MHz device clock: no wait inside a server outlasts this
 struct ZcBatch {
     unsigned params[ZC_PARAM_WORDS];   // TiledParams of the batch, as words
     unsigned tile_first;               // global number of the batch's first tile (tiles are numbered through the batches, mod 2^32)
