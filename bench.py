@@ -35,7 +35,8 @@ At N=1 the a1 line also carries, measured after the timed region: `sustained_img
 `per_batch_launches` (the same stream as 143 launches per pass), `batch_completion_us` (when the host SEES batch k of the
 fused pass complete: first / p50 / last batch, polled during >= 24 passes — the per-batch clFinish of
 heterogeneous_blur.c:538-539), `release_mode_us` (the same pass with the architectural release-ordered completion add), and
-`extra` = {one_launch_5000_images, hd1080_5x5 (configs[2]), a2_8192_1gpu (configs[4] at N=1), e2e_pcie_inclusive (host
+`extra` = {one_launch_5000_images, hd1080_5x5 (configs[2]), a2_8192_1gpu (configs[4] at N=1), copy_kernel_same_box (torch's
+elementwise copy of one pass's bytes on this box, for scale: boxes differ), e2e_pcie_inclusive (host
 buffers in -> host buffers out, batch 35 and 500 on pinned buffers and batch 35 on pageable (malloc'd) ones, the reference's own
 kind; comparable to the reference's wall clock, never `value`)}.
 At N>1 the a1 line carries BOTH multi-GPU configs: configs[3] is `value`; after its timed region the same ranks run
@@ -519,6 +520,26 @@ def main() -> None:
                 L.mi_blur_host_free(pi); L.mi_blur_host_free(po)
         del keep
         return res
+
+    def point_copy_kernel(nbytes, launches=60) -> dict:
+        """What THIS box gives a kernel that only moves the same bytes: torch's elementwise copy of `nbytes` (one pass's input) into
+        another buffer of the same size — reads nbytes, writes nbytes, like a blur pass.  Boxes of the pool differ by up to 25 % on
+        every kernel alike; this figure, taken in the same process right after the timed region, says which kind of box it was."""
+        a = torch.empty(nbytes, dtype=torch.uint8, device=dev); a.random_(0, 256)
+        b = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        warm_until = time.perf_counter() + SECONDARY_WARM_S
+        while time.perf_counter() < warm_until:
+            for _ in range(10):
+                b.copy_(a)
+            torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+        for e0, e1 in evs:
+            e0.record(); b.copy_(a); e1.record()
+        torch.cuda.synchronize()
+        us = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in evs)[launches // 2]
+        del a, b
+        return {"what": "torch elementwise copy, as many bytes read and written as one pass of the headline stream", "launch_us": round(us, 2),
+                "achieved_gbs": round(2.0 * nbytes / us / 1e3, 1), "frac": frac_of(2.0 * nbytes, us)}
 
     def guarded(name, fn):
         """A secondary point must never take the headline line down: a failure becomes {"error": ...} in its place (and a
@@ -1094,6 +1115,7 @@ def main() -> None:
             extra["hd1080_5x5"] = guarded("hd1080_5x5", lambda: point_resident(1920, 1080, 3, 2, 64, 64, 64, 300,
                                                                              "64 x 1920x1080x3 per launch, 5x5, resident pool of 64 (configs[2])"))
             extra["a2_8192_1gpu"] = guarded("a2_8192_1gpu", lambda: point_a2_1gpu(300))
+            extra["copy_kernel_same_box"] = guarded("copy_kernel", lambda: point_copy_kernel(per_gpu * h * w * c))
             extra["e2e_pcie_inclusive"] = {"batch_35": guarded("e2e batch 35", lambda: point_e2e(256, 256, 3, 1, 35, 143 * 4)),
                                            "batch_500": guarded("e2e batch 500", lambda: point_e2e(256, 256, 3, 1, 500, 40)),
                                            "batch_35_pageable": guarded("e2e batch 35 pageable", lambda: point_e2e(256, 256, 3, 1, 35, 143 * 4, pageable=True)),

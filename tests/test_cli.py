@@ -489,7 +489,8 @@ def test_bench_default_line_carries_every_single_gpu_config(pkg):
     assert d["release_mode_us"]["dispatch_us"] > d["roofline"]["avg_launch_us"] and d["release_mode_us"]["batches_counted_in"] == 143
     assert d["sustained"]["seconds"] >= 1.0 and d["sustained_img_s"] > 0
     ex = d["extra"]
-    assert set(ex) >= {"hd1080_5x5", "a2_8192_1gpu", "e2e_pcie_inclusive", "one_launch_5000_images"}
+    assert set(ex) >= {"hd1080_5x5", "a2_8192_1gpu", "e2e_pcie_inclusive", "one_launch_5000_images", "copy_kernel_same_box"}
+    assert 0 < ex["copy_kernel_same_box"]["frac"] <= 1
     assert 0 < ex["hd1080_5x5"]["frac"] <= 1 and 0 < ex["a2_8192_1gpu"]["frac"] <= 1
     assert ex["a2_8192_1gpu"]["out_fnv"] == "d283787bcc5b6dfd"             # tests/golden k3 8192x8192x3 (reference kernel)
     assert ex["e2e_pcie_inclusive"]["batch_35"]["img_s"] > 0 and ex["e2e_pcie_inclusive"]["batch_500"]["img_s"] > 0
